@@ -1,0 +1,282 @@
+// api.hip -- the extern "C" boundary (include/droid_backends_hip.h).  Host-side only: argument
+// checks, workspace carving, kernel launches on the caller's stream.  No synchronisation except
+// in droid_ba_status.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/droid_backends_hip.h"
+#include "ba_internal.hpp"
+
+namespace droid {
+// corr.hip
+int launch_corr_index_forward(const void* volume, const float* coords, void* corr, int B, int H1,
+                              int W1, int H2, int W2, int r, int dtype, hipStream_t s);
+int launch_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad, int B,
+                               int H1, int W1, int H2, int W2, int r, int dtype, hipStream_t s);
+int launch_altcorr_forward(const void* f1, const void* f2, const float* coords, void* corr, int B,
+                           int N, int H1, int W1, int H2, int W2, int C, int r, int dtype,
+                           hipStream_t s);
+int launch_altcorr_backward(const float* f1, const float* f2, const float* coords,
+                            const float* corr_grad, float* f1g, float* f2g, int B, int N, int H1,
+                            int W1, int H2, int W2, int C, int r, hipStream_t s);
+// geom.hip
+void launch_frame_distance(const float* poses, const float* disps, const float* intr,
+                           const int64_t* ii, const int64_t* jj, int E, int nbuf, int H, int W,
+                           float beta, float* dist, hipStream_t s);
+void launch_projmap(const float* poses, const float* disps, const float* intr, const int64_t* ii,
+                    const int64_t* jj, int E, int nbuf, int H, int W, float* coords, float* valid,
+                    hipStream_t s);
+void launch_iproj(const float* poses, const float* disps, const float* intr, int nm, int H, int W,
+                  float* points, hipStream_t s);
+void launch_depth_filter(const float* poses, const float* disps, const float* intr,
+                         const int64_t* ix, const float* thresh, int num, int nbuf, int H, int W,
+                         float* counter, hipStream_t s);
+// chol.hip
+void launch_chol_pack(const double* A, const double* b, double* S, int n, int ld, hipStream_t s);
+}  // namespace droid
+
+using namespace droid;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, const char* what) {
+  snprintf(g_err, sizeof(g_err), fmt, what);
+  return code;
+}
+
+static int check_hip(const char* where) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return DROID_E_HIP;
+  }
+  return DROID_OK;
+}
+
+extern "C" {
+
+int droid_abi_version(void) { return DROID_ABI_VERSION; }
+const char* droid_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------- correlation
+int droid_corr_index_forward(const void* volume, const float* coords, void* corr, int B, int H1,
+                             int W1, int H2, int W2, int radius, int dtype, void* stream) {
+  if (B < 0 || H1 <= 0 || W1 <= 0 || H2 <= 0 || W2 <= 0 || radius < 0 || radius > 7)
+    return fail(DROID_E_ARG, "corr_index_forward: bad %s", "shape/radius");
+  if (dtype < DROID_F16 || dtype > DROID_F64) return fail(DROID_E_ARG, "corr_index_forward: bad %s", "dtype");
+  if (B == 0) return DROID_OK;
+  if (!volume || !coords || !corr) return fail(DROID_E_ARG, "corr_index_forward: null %s", "pointer");
+  int rc = launch_corr_index_forward(volume, coords, corr, B, H1, W1, H2, W2, radius, dtype,
+                                     (hipStream_t)stream);
+  if (rc) return fail(rc, "corr_index_forward: %s", "unsupported configuration");
+  return check_hip("corr_index_forward");
+}
+
+int droid_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad, int B,
+                              int H1, int W1, int H2, int W2, int radius, int dtype, void* stream) {
+  if (B < 0 || H1 <= 0 || W1 <= 0 || H2 <= 0 || W2 <= 0 || radius < 0 || radius > 7)
+    return fail(DROID_E_ARG, "corr_index_backward: bad %s", "shape/radius");
+  if (dtype < DROID_F16 || dtype > DROID_F64) return fail(DROID_E_ARG, "corr_index_backward: bad %s", "dtype");
+  if (B == 0) return DROID_OK;
+  if (!coords || !corr_grad || !volume_grad) return fail(DROID_E_ARG, "corr_index_backward: null %s", "pointer");
+  int rc = launch_corr_index_backward(coords, corr_grad, volume_grad, B, H1, W1, H2, W2, radius,
+                                      dtype, (hipStream_t)stream);
+  if (rc) return fail(rc, "corr_index_backward: %s", "unsupported configuration");
+  return check_hip("corr_index_backward");
+}
+
+int droid_altcorr_forward(const void* fmap1, const void* fmap2, const float* coords, void* corr,
+                          int B, int N, int H1, int W1, int H2, int W2, int C, int radius,
+                          int dtype, void* stream) {
+  if (B < 0 || N <= 0 || H1 <= 0 || W1 <= 0 || H2 <= 0 || W2 <= 0 || C <= 0 || radius < 0 || radius > 7)
+    return fail(DROID_E_ARG, "altcorr_forward: bad %s", "shape/radius");
+  if (dtype < DROID_F16 || dtype > DROID_F64) return fail(DROID_E_ARG, "altcorr_forward: bad %s", "dtype");
+  if (B == 0) return DROID_OK;
+  if (!fmap1 || !fmap2 || !coords || !corr) return fail(DROID_E_ARG, "altcorr_forward: null %s", "pointer");
+  int rc = launch_altcorr_forward(fmap1, fmap2, coords, corr, B, N, H1, W1, H2, W2, C, radius,
+                                  dtype, (hipStream_t)stream);
+  if (rc) return fail(rc, "altcorr_forward: %s", "unsupported configuration");
+  return check_hip("altcorr_forward");
+}
+
+int droid_altcorr_backward(const float* fmap1, const float* fmap2, const float* coords,
+                           const float* corr_grad, float* fmap1_grad, float* fmap2_grad, int B,
+                           int N, int H1, int W1, int H2, int W2, int C, int radius, void* stream) {
+  if (B < 0 || N <= 0 || H1 <= 0 || W1 <= 0 || H2 <= 0 || W2 <= 0 || C <= 0 || radius < 0 || radius > 7)
+    return fail(DROID_E_ARG, "altcorr_backward: bad %s", "shape/radius");
+  if (B == 0) return DROID_OK;
+  if (!fmap1 || !fmap2 || !coords || !corr_grad || !fmap1_grad || !fmap2_grad)
+    return fail(DROID_E_ARG, "altcorr_backward: null %s", "pointer");
+  int rc = launch_altcorr_backward(fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, B, N,
+                                   H1, W1, H2, W2, C, radius, (hipStream_t)stream);
+  if (rc) return fail(rc, "altcorr_backward: %s", "unsupported configuration");
+  return check_hip("altcorr_backward");
+}
+
+// ---------------------------------------------------------------------------- bundle adjustment
+static int ba_check(int E, int nbuf, int H, int W, int t0, int t1, int M, int motion_only) {
+  if (E < 0 || nbuf <= 0 || H <= 0 || W <= 0) return fail(DROID_E_ARG, "ba: bad %s", "sizes");
+  if (t0 < 0 || t1 <= t0 || t1 > nbuf) return fail(DROID_E_ARG, "ba: bad %s", "window [t0,t1)");
+  if (M < 0 || M > nbuf) return fail(DROID_E_ARG, "ba: bad %s", "depth-slot count (eta rows)");
+  if (!motion_only && M == 0) return fail(DROID_E_ARG, "ba: %s", "eta has no rows");
+  return DROID_OK;
+}
+
+size_t droid_ba_workspace_bytes(int E, int nbuf, int H, int W, int t0, int t1, int M) {
+  BaView v;
+  if (E < 0 || nbuf <= 0 || H <= 0 || W <= 0 || t1 <= t0 || M < 0) return 0;
+  return ba_carve(v, nullptr, E, nbuf, H, W, t0, t1, M);
+}
+
+static int ba_view(BaView& v, void* ws, size_t ws_bytes, int E, int nbuf, int H, int W, int t0,
+                   int t1, int M, int motion_only) {
+  int rc = ba_check(E, nbuf, H, W, t0, t1, M, motion_only);
+  if (rc) return rc;
+  if (!ws) return fail(DROID_E_ARG, "ba: null %s", "workspace");
+  const size_t need = ba_carve(v, ws, E, nbuf, H, W, t0, t1, motion_only ? 0 : M);
+  if (ws_bytes < need) return fail(DROID_E_WORKSPACE, "ba: %s", "workspace too small");
+  return DROID_OK;
+}
+
+int droid_ba_prepare(const int64_t* ii, const int64_t* jj, int E, int nbuf, int H, int W, int M,
+                     int t0, int t1, int own0, int own1, int motion_only, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  BaView v;
+  int rc = ba_view(v, workspace, workspace_bytes, E, nbuf, H, W, t0, t1, M, motion_only);
+  if (rc) return rc;
+  if (E > 0 && (!ii || !jj)) return fail(DROID_E_ARG, "ba: null %s", "edge arrays");
+  v.own0 = own0 < 0 ? 0 : own0;
+  v.own1 = own1 > nbuf ? nbuf : own1;
+  v.motion_only = motion_only ? 1 : 0;
+  launch_prep(v, ii, jj, (hipStream_t)stream);
+  return check_hip("ba_prepare");
+}
+
+int droid_ba_build(const float* poses, const float* disps, const float* intrinsics,
+                   const float* disps_sens, const float* targets, const float* weights,
+                   const float* eta, const int64_t* ii, const int64_t* jj, int E, int nbuf, int H,
+                   int W, int M, int t0, int t1, int motion_only, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+  BaView v;
+  int rc = ba_view(v, workspace, workspace_bytes, E, nbuf, H, W, t0, t1, M, motion_only);
+  if (rc) return rc;
+  if (!poses || !disps || !intrinsics) return fail(DROID_E_ARG, "ba: null %s", "state pointer");
+  if (E > 0 && (!targets || !weights || !ii || !jj)) return fail(DROID_E_ARG, "ba: null %s", "edge data");
+  if (!motion_only && (!eta || !disps_sens)) return fail(DROID_E_ARG, "ba: null %s", "eta/disps_sens");
+  launch_build(v, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
+               motion_only != 0, (hipStream_t)stream);
+  return check_hip("ba_build");
+}
+
+int droid_ba_solve_update(float* poses, float* disps, const int64_t* ii, const int64_t* jj, int E,
+                          int nbuf, int H, int W, int M, int t0, int t1, float lm, float ep,
+                          int motion_only, float* dx_out, float* dz_out, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  (void)ii;
+  (void)jj;
+  BaView v;
+  int rc = ba_view(v, workspace, workspace_bytes, E, nbuf, H, W, t0, t1, M, motion_only);
+  if (rc) return rc;
+  if (!poses || !disps) return fail(DROID_E_ARG, "ba: null %s", "state pointer");
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
+  launch_chol_solve(v.sys, v.n, v.ld, (double)lm, (double)ep, v.xsol, v.hdr + HDR_CHOL_FAIL, s);
+  launch_update(v, poses, disps, v.xsol, dx_out, dz_out, motion_only != 0, s);
+  return check_hip("ba_solve_update");
+}
+
+int droid_ba(float* poses, float* disps, const float* intrinsics, const float* disps_sens,
+             const float* targets, const float* weights, const float* eta, const int64_t* ii,
+             const int64_t* jj, int E, int nbuf, int H, int W, int M, int t0, int t1,
+             int iterations, float lm, float ep, int motion_only, float* dx_out, float* dz_out,
+             void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = droid_ba_prepare(ii, jj, E, nbuf, H, W, M, t0, t1, 0, nbuf, motion_only, workspace,
+                            workspace_bytes, stream);
+  if (rc) return rc;
+  for (int it = 0; it < iterations; it++) {
+    rc = droid_ba_build(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, E,
+                        nbuf, H, W, M, t0, t1, motion_only, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    rc = droid_ba_solve_update(poses, disps, ii, jj, E, nbuf, H, W, M, t0, t1, lm, ep, motion_only,
+                               dx_out, dz_out, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return DROID_OK;
+}
+
+double* droid_ba_system(void* workspace, int E, int nbuf, int H, int W, int t0, int t1, int M,
+                        size_t* n_elements) {
+  BaView v;
+  if (!workspace || t1 <= t0) return nullptr;
+  ba_carve(v, workspace, E, nbuf, H, W, t0, t1, M);
+  if (n_elements) *n_elements = (size_t)v.ld * v.ld;
+  return v.sys;
+}
+
+int droid_ba_status(const void* workspace, void* stream, int* status_out, int* depth_slots_out) {
+  if (!workspace) return fail(DROID_E_ARG, "ba_status: null %s", "workspace");
+  int hdr[HDR_WORDS];
+  hipError_t e = hipMemcpyAsync(hdr, workspace, sizeof(hdr), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "ba_status: %s", hipGetErrorString(e));
+    return DROID_E_HIP;
+  }
+  if (status_out) *status_out = hdr[HDR_STATUS];
+  if (depth_slots_out) *depth_slots_out = hdr[HDR_M];
+  return DROID_OK;
+}
+
+int droid_chol_solve(const double* A, const double* b, double* x, int n, double* scratch,
+                     int* fail_flag, void* stream) {
+  if (n <= 0 || !A || !b || !x || !scratch || !fail_flag) return fail(DROID_E_ARG, "chol_solve: bad %s", "argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int ld = n + 1;
+  hipMemsetAsync(fail_flag, 0, sizeof(int), s);
+  launch_chol_pack(A, b, scratch, n, ld, s);
+  launch_chol_solve(scratch, n, ld, 0.0, 0.0, x, fail_flag, s);
+  return check_hip("chol_solve");
+}
+
+// ---------------------------------------------------------------------------- geometry
+int droid_frame_distance(const float* poses, const float* disps, const float* intrinsics,
+                         const int64_t* ii, const int64_t* jj, int E, int nbuf, int H, int W,
+                         float beta, float* dist, void* stream) {
+  if (E < 0 || nbuf <= 0 || H <= 0 || W <= 0) return fail(DROID_E_ARG, "frame_distance: bad %s", "sizes");
+  if (E == 0) return DROID_OK;
+  if (!poses || !disps || !intrinsics || !ii || !jj || !dist) return fail(DROID_E_ARG, "frame_distance: null %s", "pointer");
+  launch_frame_distance(poses, disps, intrinsics, ii, jj, E, nbuf, H, W, beta, dist, (hipStream_t)stream);
+  return check_hip("frame_distance");
+}
+
+int droid_projmap(const float* poses, const float* disps, const float* intrinsics,
+                  const int64_t* ii, const int64_t* jj, int E, int nbuf, int H, int W,
+                  float* coords, float* valid, void* stream) {
+  if (E < 0 || nbuf <= 0 || H <= 0 || W <= 0) return fail(DROID_E_ARG, "projmap: bad %s", "sizes");
+  if (E == 0) return DROID_OK;
+  if (!poses || !disps || !intrinsics || !ii || !jj || !coords || !valid) return fail(DROID_E_ARG, "projmap: null %s", "pointer");
+  launch_projmap(poses, disps, intrinsics, ii, jj, E, nbuf, H, W, coords, valid, (hipStream_t)stream);
+  return check_hip("projmap");
+}
+
+int droid_iproj(const float* poses, const float* disps, const float* intrinsics, int nm, int H,
+                int W, float* points, void* stream) {
+  if (nm < 0 || H <= 0 || W <= 0) return fail(DROID_E_ARG, "iproj: bad %s", "sizes");
+  if (nm == 0) return DROID_OK;
+  if (!poses || !disps || !intrinsics || !points) return fail(DROID_E_ARG, "iproj: null %s", "pointer");
+  launch_iproj(poses, disps, intrinsics, nm, H, W, points, (hipStream_t)stream);
+  return check_hip("iproj");
+}
+
+int droid_depth_filter(const float* poses, const float* disps, const float* intrinsics,
+                       const int64_t* ix, const float* thresh, int num, int nbuf, int H, int W,
+                       float* counter, void* stream) {
+  if (num < 0 || nbuf <= 0 || H <= 0 || W <= 0) return fail(DROID_E_ARG, "depth_filter: bad %s", "sizes");
+  if (num == 0) return DROID_OK;
+  if (!poses || !disps || !intrinsics || !ix || !thresh || !counter) return fail(DROID_E_ARG, "depth_filter: null %s", "pointer");
+  launch_depth_filter(poses, disps, intrinsics, ix, thresh, num, nbuf, H, W, counter, (hipStream_t)stream);
+  return check_hip("depth_filter");
+}
+
+}  // extern "C"

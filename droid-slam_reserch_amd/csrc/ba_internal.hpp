@@ -1,0 +1,95 @@
+// ba_internal.hpp -- workspace layout of one `ba` call, shared by the host API and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace droid {
+
+constexpr int LIN_THREADS = 256;
+constexpr int LIN_PPT = 4;                       // pixels per thread per chunk
+constexpr int LIN_CP = LIN_THREADS * LIN_PPT;    // pixels per workgroup chunk
+constexpr int SCHUR_KSPLIT = 4;                  // K (pixel) split of one SYRK tile
+constexpr int SCHUR_GRID = 2048;                 // workgroups of 4 waves, grid-stride over tiles
+constexpr int CHOL_NB = 64;                      // Cholesky block size
+
+enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4, HDR_WORDS = 16 };
+enum { STATUS_BAD_INDEX = 1, STATUS_ETA_ROWS = 2, STATUS_CHOL_FAIL = 4 };
+
+// Plain-old-data view of the workspace, passed to kernels by value.
+struct BaView {
+  int E, nbuf, H, W, HW;
+  int t0, t1, P, M;        // window, poses in it, depth slots the host sized the buffers for
+  int n, ld;               // n = 6P unknowns; system is ld x ld with ld = n + 1 (row n = rhs)
+  int nch;                 // pixel chunks of the linearisation kernel
+  int own0, own1;          // frames whose depth this rank owns
+  int motion_only;         // prep: validate indices only, no depth slots
+  int* hdr;                // [HDR_WORDS] status, slot count, ...
+  int* slot_of;            // [nbuf] frame -> depth slot or -1
+  int* kx;                 // [nbuf] slot -> frame (sorted)
+  int* seg_ptr;            // [nbuf+1] CSR of edges by slot
+  int* seg_edge;           // [E]
+  int* cursor;             // [nbuf+1] scratch
+  int* ent_ptr;            // [nbuf+1] CSR of Schur entries by slot
+  int* ent_row;            // [M+E] row of Erows
+  int* ent_pose;           // [M+E] pose index in the window
+  int* wk_ptr;             // [nbuf+1] CSR of SYRK tile pairs by slot
+  float* Hpart;            // [E][nch][32] per-(edge,chunk) partial Hjj (21) + vj (6)
+  float* Q;                // [M][HW] 1/C
+  float* w;                // [M][HW]
+  float* Erows;            // [M+E][6][HW]: self rows Ei, then Eij rows
+  double* sys;             // [ld][ld] reduced camera system, lower triangle, row n = rhs
+  double* xsol;            // [ld] solve scratch / solution
+  float* dx;               // [P][6]
+};
+
+struct BaSizes {
+  size_t total;
+};
+
+// Carves `ws` (may be null: size query only) into the view.  Host-only arithmetic.
+inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t0, int t1, int M) {
+  v.E = E; v.nbuf = nbuf; v.H = H; v.W = W; v.HW = H * W;
+  v.t0 = t0; v.t1 = t1; v.P = t1 - t0; v.M = M;
+  v.n = 6 * v.P; v.ld = v.n + 1;
+  v.nch = (v.HW + LIN_CP - 1) / LIN_CP;
+  v.own0 = 0; v.own1 = nbuf; v.motion_only = 0;
+  size_t off = 0;
+  char* base = static_cast<char*>(ws);
+  auto take = [&](size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += (bytes + 255) & ~size_t(255);
+    return p;
+  };
+  v.hdr = static_cast<int*>(take(sizeof(int) * HDR_WORDS));
+  v.slot_of = static_cast<int*>(take(sizeof(int) * (nbuf + 1)));
+  v.kx = static_cast<int*>(take(sizeof(int) * (nbuf + 1)));
+  v.seg_ptr = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
+  v.seg_edge = static_cast<int*>(take(sizeof(int) * (E + 1)));
+  v.cursor = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
+  v.ent_ptr = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
+  v.ent_row = static_cast<int*>(take(sizeof(int) * ((size_t)M + E + 1)));
+  v.ent_pose = static_cast<int*>(take(sizeof(int) * ((size_t)M + E + 1)));
+  v.wk_ptr = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
+  v.Hpart = static_cast<float*>(take(sizeof(float) * ((size_t)E * v.nch * 32 + 32)));
+  v.Q = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
+  v.w = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
+  v.Erows = static_cast<float*>(take(sizeof(float) * (M > 0 ? ((size_t)M + E) * 6 * v.HW + 4 : 4)));
+  v.sys = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld * v.ld + 1)));
+  v.xsol = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld + 1)));
+  v.dx = static_cast<float*>(take(sizeof(float) * ((size_t)v.n + 8)));
+  return off;
+}
+
+// kernels' launchers (ba_kernels.hip / chol.hip)
+void launch_prep(const BaView& v, const int64_t* ii, const int64_t* jj, hipStream_t s);
+void launch_build(const BaView& v, const float* poses, const float* disps, const float* intr,
+                  const float* sens, const float* targets, const float* weights, const float* eta,
+                  const int64_t* ii, const int64_t* jj, bool motion_only, hipStream_t s);
+void launch_update(const BaView& v, float* poses, float* disps, const double* x, float* dx_out,
+                   float* dz_out, bool motion_only, hipStream_t s);
+// In-place damped Cholesky of the lower triangle of sys (ld x ld, row n = rhs) + solve -> x [n].
+void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
+                       hipStream_t s);
+
+}  // namespace droid

@@ -1,0 +1,358 @@
+// corr.hip -- correlation lookups on gfx950.
+//
+//  * corr_index_forward/backward: bilinear (2r+1)^2 window lookup in a precomputed all-pairs
+//    volume (/root/reference/src/correlation_kernels.cu:19-124).  Pure gather, HBM bound.
+//  * altcorr_forward/backward: the same lookup with the correlation computed on the fly from
+//    channels-last feature maps (/root/reference/src/altcorr_kernel.cu:27-286).
+//
+// Arithmetic contract (restated from the reference, checked bit-for-bit against oracle/corr.py
+// for f16/f32 volumes): every bilinear weight is formed in fp32 and rounded to the element type,
+// each product is rounded to the element type, and the four contributions of one output are
+// added in the order taps (a,c), (a,c+1), (a+1,c), (a+1,c+1) with a rounding after every add
+// (correlation_kernels.cu:46-66; a = x offset, c = y offset).
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/droid_backends_hip.h"
+
+namespace droid {
+
+// ---- element-type arithmetic with the reference's rounding points -------------------------
+template <typename T> struct Elem;
+template <> struct Elem<__half> {
+  typedef float work;  // c10::Half operators compute in fp32 and round to half
+  static __device__ __forceinline__ float load(const __half* p) { return __half2float(*p); }
+  static __device__ __forceinline__ float round(float x) { return __half2float(__float2half_rn(x)); }
+  static __device__ __forceinline__ void store(__half* p, float x) { *p = __float2half_rn(x); }
+  static __device__ __forceinline__ float mul(float a, float b) { return round(__fmul_rn(a, b)); }
+  static __device__ __forceinline__ float add(float a, float b) { return round(__fadd_rn(a, b)); }
+};
+template <> struct Elem<float> {
+  typedef float work;
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ float round(float x) { return x; }
+  static __device__ __forceinline__ void store(float* p, float x) { *p = x; }
+  static __device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
+  static __device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
+};
+template <> struct Elem<double> {
+  typedef double work;
+  static __device__ __forceinline__ double load(const double* p) { return *p; }
+  static __device__ __forceinline__ double round(double x) { return x; }
+  static __device__ __forceinline__ void store(double* p, double x) { *p = x; }
+  static __device__ __forceinline__ double mul(double a, double b) { return __dmul_rn(a, b); }
+  static __device__ __forceinline__ double add(double a, double b) { return __dadd_rn(a, b); }
+};
+
+struct Bilin {
+  int x1, y1;       // top-left integer tap = floor(coord) - r
+  float dx, dy;     // fractional parts, fp32 (ck:42-43)
+};
+
+__device__ __forceinline__ Bilin bilin_setup(float x0, float y0, int r) {
+  Bilin b;
+  const float fx = floorf(x0), fy = floorf(y0);
+  b.dx = x0 - fx;
+  b.dy = y0 - fy;
+  // clamp far-away coordinates before the int conversion: any window that far out is empty
+  const float lim = 1.0e6f;
+  b.x1 = (int)fminf(fmaxf(fx, -lim), lim) - r;
+  b.y1 = (int)fminf(fmaxf(fy, -lim), lim) - r;
+  if (!(x0 == x0) || !(y0 == y0)) { b.x1 = -2000000; b.y1 = -2000000; }
+  return b;
+}
+
+// ---- corr_index_forward ------------------------------------------------------------------
+// One thread per query pixel, 64 consecutive pixels per wave: the (2r+1)^2 outputs of a plane
+// offset are stores of 64 consecutive elements; the window rows are 2r+2 contiguous taps each.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void corr_index_forward_kernel(const T* __restrict__ volume,
+                                                                 const float* __restrict__ coords,
+                                                                 T* __restrict__ corr, int H1W1,
+                                                                 int H2, int W2) {
+  typedef typename Elem<T>::work work;
+  constexpr int RD = 2 * R + 1, NT = RD + 1;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= H1W1) return;
+  const float x0 = coords[((size_t)b * 2 + 0) * H1W1 + pix];
+  const float y0 = coords[((size_t)b * 2 + 1) * H1W1 + pix];
+  const Bilin bl = bilin_setup(x0, y0, R);
+  const T* plane = volume + ((size_t)b * H1W1 + pix) * ((size_t)H2 * W2);
+
+  work tap[NT][NT];  // [row j (y)][col i (x)]
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    const int y1 = bl.y1 + j;
+    const bool rowok = (y1 >= 0) && (y1 < H2);
+    const T* row = plane + (size_t)(rowok ? y1 : 0) * W2;
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+      const int x1 = bl.x1 + i;
+      const bool ok = rowok && (x1 >= 0) && (x1 < W2);
+      tap[j][i] = ok ? Elem<T>::load(row + x1) : (work)0;
+    }
+  }
+  const float one = 1.0f;
+  // weights rounded to the element type (ck:55-65)
+  const work w00 = Elem<T>::round((work)((one - bl.dx) * (one - bl.dy)));  // tap (a  ,c  )
+  const work w01 = Elem<T>::round((work)((one - bl.dx) * bl.dy));          // tap (a  ,c+1)
+  const work w10 = Elem<T>::round((work)(bl.dx * (one - bl.dy)));          // tap (a+1,c  )
+  const work w11 = Elem<T>::round((work)(bl.dx * bl.dy));                  // tap (a+1,c+1)
+  T* out = corr + (size_t)b * RD * RD * H1W1 + pix;
+#pragma unroll
+  for (int a = 0; a < RD; a++) {
+#pragma unroll
+    for (int c = 0; c < RD; c++) {
+      work acc = Elem<T>::mul(tap[c][a], w00);  // 0 + p == p exactly
+      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a], w01));
+      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c][a + 1], w10));
+      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a + 1], w11));
+      Elem<T>::store(out + (size_t)(a * RD + c) * H1W1, acc);
+    }
+  }
+}
+
+// Any radius (slow path): taps are re-read per output.
+template <typename T>
+__global__ __launch_bounds__(256) void corr_index_forward_generic(const T* __restrict__ volume,
+                                                                  const float* __restrict__ coords,
+                                                                  T* __restrict__ corr, int H1W1,
+                                                                  int H2, int W2, int r) {
+  typedef typename Elem<T>::work work;
+  const int rd = 2 * r + 1;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= H1W1) return;
+  const Bilin bl = bilin_setup(coords[((size_t)b * 2 + 0) * H1W1 + pix],
+                               coords[((size_t)b * 2 + 1) * H1W1 + pix], r);
+  const T* plane = volume + ((size_t)b * H1W1 + pix) * ((size_t)H2 * W2);
+  auto tapv = [&](int i, int j) -> work {
+    const int x1 = bl.x1 + i, y1 = bl.y1 + j;
+    if (x1 < 0 || x1 >= W2 || y1 < 0 || y1 >= H2) return (work)0;
+    return Elem<T>::load(plane + (size_t)y1 * W2 + x1);
+  };
+  const work w00 = Elem<T>::round((work)((1.0f - bl.dx) * (1.0f - bl.dy)));
+  const work w01 = Elem<T>::round((work)((1.0f - bl.dx) * bl.dy));
+  const work w10 = Elem<T>::round((work)(bl.dx * (1.0f - bl.dy)));
+  const work w11 = Elem<T>::round((work)(bl.dx * bl.dy));
+  T* out = corr + (size_t)b * rd * rd * H1W1 + pix;
+  for (int a = 0; a < rd; a++)
+    for (int c = 0; c < rd; c++) {
+      work acc = Elem<T>::mul(tapv(a, c), w00);
+      acc = Elem<T>::add(acc, Elem<T>::mul(tapv(a, c + 1), w01));
+      acc = Elem<T>::add(acc, Elem<T>::mul(tapv(a + 1, c), w10));
+      acc = Elem<T>::add(acc, Elem<T>::mul(tapv(a + 1, c + 1), w11));
+      Elem<T>::store(out + (size_t)(a * rd + c) * H1W1, acc);
+    }
+}
+
+template <typename T>
+static int corr_index_forward_t(const void* volume, const float* coords, void* corr, int B, int H1,
+                                int W1, int H2, int W2, int r, hipStream_t s) {
+  const int HW = H1 * W1;
+  dim3 grid((HW + 255) / 256, B), block(256);
+  const T* v = static_cast<const T*>(volume);
+  T* c = static_cast<T*>(corr);
+  if (r == 3)
+    hipLaunchKernelGGL((corr_index_forward_kernel<T, 3>), grid, block, 0, s, v, coords, c, HW, H2, W2);
+  else if (r == 4)
+    hipLaunchKernelGGL((corr_index_forward_kernel<T, 4>), grid, block, 0, s, v, coords, c, HW, H2, W2);
+  else
+    hipLaunchKernelGGL((corr_index_forward_generic<T>), grid, block, 0, s, v, coords, c, HW, H2, W2, r);
+  return 0;
+}
+
+int launch_corr_index_forward(const void* volume, const float* coords, void* corr, int B, int H1,
+                              int W1, int H2, int W2, int r, int dtype, hipStream_t s) {
+  if (B > 65535) return DROID_E_ARG;
+  switch (dtype) {
+    case DROID_F16: return corr_index_forward_t<__half>(volume, coords, corr, B, H1, W1, H2, W2, r, s);
+    case DROID_F32: return corr_index_forward_t<float>(volume, coords, corr, B, H1, W1, H2, W2, r, s);
+    case DROID_F64: return corr_index_forward_t<double>(volume, coords, corr, B, H1, W1, H2, W2, r, s);
+  }
+  return DROID_E_ARG;
+}
+
+// ---- corr_index_backward (ck:73-124): each query scatters into its own plane -> no races ---
+template <typename T>
+__global__ __launch_bounds__(256) void corr_index_backward_kernel(const float* __restrict__ coords,
+                                                                  const T* __restrict__ corr_grad,
+                                                                  T* __restrict__ volume_grad,
+                                                                  int H1W1, int H2, int W2, int r) {
+  typedef typename Elem<T>::work work;
+  const int rd = 2 * r + 1;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= H1W1) return;
+  const Bilin bl = bilin_setup(coords[((size_t)b * 2 + 0) * H1W1 + pix],
+                               coords[((size_t)b * 2 + 1) * H1W1 + pix], r);
+  T* plane = volume_grad + ((size_t)b * H1W1 + pix) * ((size_t)H2 * W2);
+  const T* g = corr_grad + (size_t)b * rd * rd * H1W1 + pix;
+  const work w11 = Elem<T>::round((work)(bl.dx * bl.dy));
+  const work w10 = Elem<T>::round((work)(bl.dx * (1.0f - bl.dy)));
+  const work w01 = Elem<T>::round((work)((1.0f - bl.dx) * bl.dy));
+  const work w00 = Elem<T>::round((work)((1.0f - bl.dx) * (1.0f - bl.dy)));
+  for (int i = 0; i < rd + 1; i++)
+    for (int j = 0; j < rd + 1; j++) {
+      const int x1 = bl.x1 + i, y1 = bl.y1 + j;
+      if (x1 < 0 || x1 >= W2 || y1 < 0 || y1 >= H2) continue;
+      work acc = (work)0;  // ck:106-117, same order and rounding points
+      if (i > 0 && j > 0)
+        acc = Elem<T>::add(acc, Elem<T>::mul(Elem<T>::load(g + (size_t)((i - 1) * rd + (j - 1)) * H1W1), w11));
+      if (i > 0 && j < rd)
+        acc = Elem<T>::add(acc, Elem<T>::mul(Elem<T>::load(g + (size_t)((i - 1) * rd + j) * H1W1), w10));
+      if (i < rd && j > 0)
+        acc = Elem<T>::add(acc, Elem<T>::mul(Elem<T>::load(g + (size_t)(i * rd + (j - 1)) * H1W1), w01));
+      if (i < rd && j < rd)
+        acc = Elem<T>::add(acc, Elem<T>::mul(Elem<T>::load(g + (size_t)(i * rd + j) * H1W1), w00));
+      Elem<T>::store(plane + (size_t)y1 * W2 + x1, acc);
+    }
+}
+
+template <typename T>
+static int corr_index_backward_t(const float* coords, const void* corr_grad, void* volume_grad,
+                                 int B, int H1, int W1, int H2, int W2, int r, hipStream_t s) {
+  const int HW = H1 * W1;
+  hipMemsetAsync(volume_grad, 0, sizeof(T) * (size_t)B * HW * H2 * W2, s);
+  hipLaunchKernelGGL((corr_index_backward_kernel<T>), dim3((HW + 255) / 256, B), dim3(256), 0, s,
+                     coords, static_cast<const T*>(corr_grad), static_cast<T*>(volume_grad), HW, H2,
+                     W2, r);
+  return 0;
+}
+
+int launch_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad, int B,
+                               int H1, int W1, int H2, int W2, int r, int dtype, hipStream_t s) {
+  if (B > 65535) return DROID_E_ARG;
+  switch (dtype) {
+    case DROID_F16: return corr_index_backward_t<__half>(coords, corr_grad, volume_grad, B, H1, W1, H2, W2, r, s);
+    case DROID_F32: return corr_index_backward_t<float>(coords, corr_grad, volume_grad, B, H1, W1, H2, W2, r, s);
+    case DROID_F64: return corr_index_backward_t<double>(coords, corr_grad, volume_grad, B, H1, W1, H2, W2, r, s);
+  }
+  return DROID_E_ARG;
+}
+
+// ---- altcorr_forward (generic path) -------------------------------------------------------
+// 16 lanes per query pixel, 4 queries per wave; every lane owns C/16 channels (strided by 16
+// float4s so that a query's 16 lanes read one contiguous run of the channels-last row).
+// corr(oy,ox) = sum over the 4 neighbouring taps of <f1, f2(tap)> * bilinear weight, channel of
+// the output = ox*(2r+1)+oy (ak:109-142).
+template <typename T>
+__global__ __launch_bounds__(256) void altcorr_forward_generic(const T* __restrict__ fmap1,
+                                                               const T* __restrict__ fmap2,
+                                                               const float* __restrict__ coords,
+                                                               T* __restrict__ corr, int N, int H1W1,
+                                                               int H2, int W2, int C, int r) {
+  typedef typename Elem<T>::work work;
+  const int rd = 2 * r + 1;
+  const int sub = threadIdx.x & 15;
+  const int q = (blockIdx.x * 256 + threadIdx.x) >> 4;  // query index within (b, n)
+  const int n = blockIdx.y, b = blockIdx.z;
+  const bool qok = q < H1W1;
+  const int pix = qok ? q : 0;
+  const float* cp = coords + (((size_t)b * N + n) * H1W1 + pix) * 2;
+  const Bilin bl = bilin_setup(cp[0], cp[1], r);
+  const T* f1 = fmap1 + ((size_t)b * H1W1 + pix) * C;
+  const T* f2b = fmap2 + (size_t)b * H2 * W2 * C;
+  T* out = corr + (((size_t)b * N + n) * rd * rd) * H1W1 + pix;
+  const work wnw = Elem<T>::round((work)(bl.dy * bl.dx));                  // ak:119-122
+  const work wne = Elem<T>::round((work)(bl.dy * (1.0f - bl.dx)));
+  const work wsw = Elem<T>::round((work)((1.0f - bl.dy) * bl.dx));
+  const work wse = Elem<T>::round((work)((1.0f - bl.dy) * (1.0f - bl.dx)));
+  // dot products of the (rd+1)^2 taps, one row of taps at a time, two rows live
+  for (int ox = 0; ox < rd; ox++) {
+    for (int oy = 0; oy < rd; oy++) {
+      work s4[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int iy = oy + (t >> 1), ix = ox + (t & 1);
+        const int h2 = bl.y1 + iy, w2 = bl.x1 + ix;
+        work s = (work)0;
+        if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
+          const T* f2 = f2b + ((size_t)h2 * W2 + w2) * C;
+          for (int c = sub; c < C; c += 16) s += (work)Elem<T>::load(f1 + c) * (work)Elem<T>::load(f2 + c);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        s4[t] = Elem<T>::round(s);
+      }
+      // taps: t=0 (oy,ox) se, t=1 (oy,ox+1) sw, t=2 (oy+1,ox) ne, t=3 (oy+1,ox+1) nw
+      work acc = Elem<T>::mul(s4[0], wse);
+      acc = Elem<T>::add(acc, Elem<T>::mul(s4[1], wsw));
+      acc = Elem<T>::add(acc, Elem<T>::mul(s4[2], wne));
+      acc = Elem<T>::add(acc, Elem<T>::mul(s4[3], wnw));
+      if (qok && sub == 0) Elem<T>::store(out + (size_t)(ox * rd + oy) * H1W1, acc);
+    }
+  }
+}
+
+template <typename T>
+static int altcorr_forward_t(const void* f1, const void* f2, const float* coords, void* corr, int B,
+                             int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s) {
+  const int HW = H1 * W1;
+  dim3 grid((HW * 16 + 255) / 256, N, B), block(256);
+  hipLaunchKernelGGL((altcorr_forward_generic<T>), grid, block, 0, s, static_cast<const T*>(f1),
+                     static_cast<const T*>(f2), coords, static_cast<T*>(corr), N, HW, H2, W2, C, r);
+  return 0;
+}
+
+int launch_altcorr_forward(const void* f1, const void* f2, const float* coords, void* corr, int B,
+                           int N, int H1, int W1, int H2, int W2, int C, int r, int dtype,
+                           hipStream_t s) {
+  if (B > 65535 || N > 65535) return DROID_E_ARG;
+  switch (dtype) {
+    case DROID_F16: return altcorr_forward_t<__half>(f1, f2, coords, corr, B, N, H1, W1, H2, W2, C, r, s);
+    case DROID_F32: return altcorr_forward_t<float>(f1, f2, coords, corr, B, N, H1, W1, H2, W2, C, r, s);
+    case DROID_F64: return altcorr_forward_t<double>(f1, f2, coords, corr, B, N, H1, W1, H2, W2, C, r, s);
+  }
+  return DROID_E_ARG;
+}
+
+// ---- altcorr_backward (ak:152-286), fp32, atomics into pre-zeroed gradients ----------------
+__global__ __launch_bounds__(256) void altcorr_backward_kernel(
+    const float* __restrict__ fmap1, const float* __restrict__ fmap2,
+    const float* __restrict__ coords, const float* __restrict__ corr_grad,
+    float* __restrict__ fmap1_grad, float* __restrict__ fmap2_grad, int N, int H1W1, int H2, int W2,
+    int C, int r) {
+  const int rd = 2 * r + 1;
+  const int sub = threadIdx.x & 15;
+  const int q = (blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int n = blockIdx.y, b = blockIdx.z;
+  if (q >= H1W1) return;
+  const float* cp = coords + (((size_t)b * N + n) * H1W1 + q) * 2;
+  const Bilin bl = bilin_setup(cp[0], cp[1], r);
+  const float* f1 = fmap1 + ((size_t)b * H1W1 + q) * C;
+  float* g1 = fmap1_grad + ((size_t)b * H1W1 + q) * C;
+  const float* cg = corr_grad + (((size_t)b * N + n) * rd * rd) * H1W1 + q;
+  for (int iy = 0; iy < rd + 1; iy++)
+    for (int ix = 0; ix < rd + 1; ix++) {
+      const int h2 = bl.y1 + iy, w2 = bl.x1 + ix;
+      if (h2 < 0 || h2 >= H2 || w2 < 0 || w2 >= W2) continue;
+      float g = 0.f;  // ak:228-246
+      if (iy > 0 && ix > 0) g += cg[(size_t)((iy - 1) + rd * (ix - 1)) * H1W1] * (bl.dy * bl.dx);
+      if (iy > 0 && ix < rd) g += cg[(size_t)((iy - 1) + rd * ix) * H1W1] * (bl.dy * (1.f - bl.dx));
+      if (iy < rd && ix > 0) g += cg[(size_t)(iy + rd * (ix - 1)) * H1W1] * ((1.f - bl.dy) * bl.dx);
+      if (iy < rd && ix < rd) g += cg[(size_t)(iy + rd * ix) * H1W1] * ((1.f - bl.dy) * (1.f - bl.dx));
+      const float* f2 = fmap2 + (((size_t)b * H2 + h2) * W2 + w2) * C;
+      float* g2 = fmap2_grad + (((size_t)b * H2 + h2) * W2 + w2) * C;
+      for (int c = sub; c < C; c += 16) {
+        atomicAdd(&g1[c], g * f2[c]);
+        atomicAdd(&g2[c], g * f1[c]);
+      }
+    }
+}
+
+int launch_altcorr_backward(const float* f1, const float* f2, const float* coords,
+                            const float* corr_grad, float* f1g, float* f2g, int B, int N, int H1,
+                            int W1, int H2, int W2, int C, int r, hipStream_t s) {
+  if (B > 65535 || N > 65535) return DROID_E_ARG;
+  const int HW = H1 * W1;
+  hipLaunchKernelGGL(altcorr_backward_kernel, dim3((HW * 16 + 255) / 256, N, B), dim3(256), 0, s, f1,
+                     f2, coords, corr_grad, f1g, f2g, N, HW, H2, W2, C, r);
+  return 0;
+}
+
+}  // namespace droid

@@ -1,0 +1,198 @@
+// geom.hip -- the geometry operators of the droid_backends ABI besides `ba`:
+// frame_distance, projmap, iproj, depth_filter (/root/reference/src/droid_kernels.cu:427-850).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "se3.hpp"
+
+namespace droid {
+
+__device__ __forceinline__ float wave_sum(float s) {
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  return s;
+}
+
+// frame_distance_kernel dk:518-657: mean induced flow, beta * full + (1-beta) * translation-only.
+// One workgroup per edge; three wave-shuffle reductions instead of three 256-float LDS trees.
+__global__ __launch_bounds__(256) void frame_distance_kernel(
+    const float* __restrict__ poses, const float* __restrict__ disps,
+    const float* __restrict__ intrinsics, const int64_t* __restrict__ ii,
+    const int64_t* __restrict__ jj, float* __restrict__ dist, int nbuf, int H, int W, float beta) {
+  __shared__ float red[3][4];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const int64_t i64 = ii[e], j64 = jj[e];
+  if (i64 < 0 || i64 >= nbuf || j64 < 0 || j64 >= nbuf) {
+    if (tid == 0) dist[e] = 1000.0f;
+    return;
+  }
+  const int ix = (int)i64, jx = (int)j64;
+  const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  const Rel T = rel_pose_plain(poses, ix, jx);
+  const int HW = H * W;
+  float accum = 0.f, valid = 0.f, total = 0.f;
+  for (int k = tid; k < HW; k += 256) {
+    const float u = (float)(k % W), v = (float)(k / W);
+    const float d0 = disps[(size_t)ix * HW + k];
+    float Xj[4];
+    transform_pixel(K, T, u, v, d0, Xj);
+    float du = K.fx * (Xj[0] / Xj[2]) + K.cx - u;
+    float dv = K.fy * (Xj[1] / Xj[2]) + K.cy - v;
+    float d = sqrtf(du * du + dv * dv);
+    total += beta;
+    if (Xj[2] > DROID_MIN_DEPTH) {
+      accum += beta * d;
+      valid += beta;
+    }
+    const float X0 = (u - K.cx) / K.fx, X1 = (v - K.cy) / K.fy;
+    Xj[0] = X0 + d0 * T.t[0];
+    Xj[1] = X1 + d0 * T.t[1];
+    Xj[2] = 1.f + d0 * T.t[2];
+    du = K.fx * (Xj[0] / Xj[2]) + K.cx - u;
+    dv = K.fy * (Xj[1] / Xj[2]) + K.cy - v;
+    d = sqrtf(du * du + dv * dv);
+    total += (1.f - beta);
+    if (Xj[2] > DROID_MIN_DEPTH) {
+      accum += (1.f - beta) * d;
+      valid += (1.f - beta);
+    }
+  }
+  accum = wave_sum(accum);
+  valid = wave_sum(valid);
+  total = wave_sum(total);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = accum;
+    red[1][tid >> 6] = valid;
+    red[2][tid >> 6] = total;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const float vl = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float tt = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    dist[e] = (vl / (tt + 1e-8f) < 0.75f) ? 1000.0f : a / vl;  // dk:655
+  }
+}
+
+// projmap_kernel dk:427-516
+__global__ __launch_bounds__(256) void projmap_kernel(
+    const float* __restrict__ poses, const float* __restrict__ disps,
+    const float* __restrict__ intrinsics, const int64_t* __restrict__ ii,
+    const int64_t* __restrict__ jj, float* __restrict__ coords, float* __restrict__ valid, int nbuf,
+    int H, int W) {
+  const int e = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W;
+  if (k >= HW) return;
+  const int64_t i64 = ii[e], j64 = jj[e];
+  if (i64 < 0 || i64 >= nbuf || j64 < 0 || j64 >= nbuf) return;
+  const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  const Rel T = rel_pose_plain(poses, (int)i64, (int)j64);
+  const float u = (float)(k % W), v = (float)(k / W);
+  float Xj[4];
+  transform_pixel(K, T, u, v, disps[(size_t)i64 * HW + k], Xj);
+  float cu = u, cv = v;
+  if (Xj[2] > 0.01f) {
+    cu = K.fx * (Xj[0] / Xj[2]) + K.cx;
+    cv = K.fy * (Xj[1] / Xj[2]) + K.cy;
+  }
+  float* c = coords + ((size_t)e * HW + k) * 3;
+  c[0] = cu;
+  c[1] = cv;
+  c[2] = 0.f;
+  valid[(size_t)e * HW + k] = (Xj[2] > DROID_MIN_DEPTH) ? 1.0f : 0.0f;
+}
+
+// iproj_kernel dk:779-850
+__global__ __launch_bounds__(256) void iproj_kernel(const float* __restrict__ poses,
+                                                    const float* __restrict__ disps,
+                                                    const float* __restrict__ intrinsics,
+                                                    float* __restrict__ points, int H, int W) {
+  const int f = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W;
+  if (k >= HW) return;
+  const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  Rel T;
+  for (int n = 0; n < 3; n++) T.t[n] = poses[7 * (size_t)f + n];
+  for (int n = 0; n < 4; n++) T.q[n] = poses[7 * (size_t)f + 3 + n];
+  float Xj[4];
+  transform_pixel(K, T, (float)(k % W), (float)(k / W), disps[(size_t)f * HW + k], Xj);
+  float* p = points + ((size_t)f * HW + k) * 3;
+  p[0] = Xj[0] / Xj[3];
+  p[1] = Xj[1] / Xj[3];
+  p[2] = Xj[2] / Xj[3];
+}
+
+// depth_filter_kernel dk:661-775: count of the 6 temporal neighbours whose depth agrees.
+// The reference adds with atomicAdd over a (num,6,tiles) grid; here one thread owns a pixel and
+// loops over the neighbours, so the count is a plain register sum.
+__global__ __launch_bounds__(256) void depth_filter_kernel(
+    const float* __restrict__ poses, const float* __restrict__ disps,
+    const float* __restrict__ intrinsics, const int64_t* __restrict__ inds,
+    const float* __restrict__ thresh, float* __restrict__ counter, int nbuf, int H, int W) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W;
+  if (k >= HW) return;
+  const int ix = (int)inds[b];
+  float cnt = 0.f;
+  if (ix >= 0 && ix < nbuf) {
+    const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+    const float t = thresh[b];
+    const float ui = (float)(k % W), vi = (float)(k / W);
+    const float di = disps[(size_t)ix * HW + k];
+    for (int nb = 0; nb < 6; nb++) {
+      const int jx = (nb < 3) ? ix - nb - 1 : ix + nb;  // dk:695
+      if (jx < 0 || jx >= nbuf) continue;
+      const Rel T = rel_pose_plain(poses, ix, jx);
+      float Xj[4];
+      transform_pixel(K, T, ui, vi, di, Xj);
+      const float uj = K.fx * (Xj[0] / Xj[2]) + K.cx;
+      const float vj = K.fy * (Xj[1] / Xj[2]) + K.cy;
+      const float dj = Xj[3] / Xj[2];
+      const int u0 = (int)floorf(uj), v0 = (int)floorf(vj);
+      if (u0 >= 0 && v0 >= 0 && u0 < W - 1 && v0 < H - 1) {
+        const float* dp = disps + (size_t)jx * HW;
+        const float d00 = dp[(v0 + 0) * W + u0 + 0], d01 = dp[(v0 + 0) * W + u0 + 1];
+        const float d10 = dp[(v0 + 1) * W + u0 + 0], d11 = dp[(v0 + 1) * W + u0 + 1];
+        const float idj = 1.0f / dj;
+        if (fabsf(idj - 1.0f / d00) < t) cnt += 1.f;
+        else if (fabsf(idj - 1.0f / d01) < t) cnt += 1.f;
+        else if (fabsf(idj - 1.0f / d10) < t) cnt += 1.f;
+        else if (fabsf(idj - 1.0f / d11) < t) cnt += 1.f;
+      }
+    }
+  }
+  counter[(size_t)b * HW + k] = cnt;
+}
+
+void launch_frame_distance(const float* poses, const float* disps, const float* intr,
+                           const int64_t* ii, const int64_t* jj, int E, int nbuf, int H, int W,
+                           float beta, float* dist, hipStream_t s) {
+  hipLaunchKernelGGL(frame_distance_kernel, dim3(E), dim3(256), 0, s, poses, disps, intr, ii, jj,
+                     dist, nbuf, H, W, beta);
+}
+
+void launch_projmap(const float* poses, const float* disps, const float* intr, const int64_t* ii,
+                    const int64_t* jj, int E, int nbuf, int H, int W, float* coords, float* valid,
+                    hipStream_t s) {
+  hipMemsetAsync(coords, 0, sizeof(float) * (size_t)E * H * W * 3, s);
+  hipMemsetAsync(valid, 0, sizeof(float) * (size_t)E * H * W, s);
+  hipLaunchKernelGGL(projmap_kernel, dim3((H * W + 255) / 256, E), dim3(256), 0, s, poses, disps,
+                     intr, ii, jj, coords, valid, nbuf, H, W);
+}
+
+void launch_iproj(const float* poses, const float* disps, const float* intr, int nm, int H, int W,
+                  float* points, hipStream_t s) {
+  hipLaunchKernelGGL(iproj_kernel, dim3((H * W + 255) / 256, nm), dim3(256), 0, s, poses, disps,
+                     intr, points, H, W);
+}
+
+void launch_depth_filter(const float* poses, const float* disps, const float* intr,
+                         const int64_t* ix, const float* thresh, int num, int nbuf, int H, int W,
+                         float* counter, hipStream_t s) {
+  hipLaunchKernelGGL(depth_filter_kernel, dim3((H * W + 255) / 256, num), dim3(256), 0, s, poses,
+                     disps, intr, ix, thresh, counter, nbuf, H, W);
+}
+
+}  // namespace droid

@@ -1,0 +1,184 @@
+// se3.hpp -- unit-quaternion SE3 device helpers and the per-pixel projective geometry shared by
+// the BA and geometry kernels.  Restates the arithmetic of
+// /root/reference/src/droid_kernels.cu:58-175 (group ops) and :290-354 (projection + Jacobians).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define DROID_MIN_DEPTH 0.25f  // droid_kernels.cu:26
+
+namespace droid {
+
+struct Intr {
+  float fx, fy, cx, cy;
+};
+
+struct Rel {       // relative transform of one edge
+  float t[3];
+  float q[4];
+};
+
+__device__ __forceinline__ void act_so3(const float* q, const float* X, float* Y) {  // dk:58-68
+  float uv0 = 2.0f * (q[1] * X[2] - q[2] * X[1]);
+  float uv1 = 2.0f * (q[2] * X[0] - q[0] * X[2]);
+  float uv2 = 2.0f * (q[0] * X[1] - q[1] * X[0]);
+  Y[0] = X[0] + q[3] * uv0 + (q[1] * uv2 - q[2] * uv1);
+  Y[1] = X[1] + q[3] * uv1 + (q[2] * uv0 - q[0] * uv2);
+  Y[2] = X[2] + q[3] * uv2 + (q[0] * uv1 - q[1] * uv0);
+}
+
+// Y = Adj(T)^T X, dk:79-94
+__device__ __forceinline__ void adj_se3(const float* t, const float* q, const float* X, float* Y) {
+  float qinv[4] = {-q[0], -q[1], -q[2], q[3]};
+  act_so3(qinv, &X[0], &Y[0]);
+  act_so3(qinv, &X[3], &Y[3]);
+  float u[3], v[3];
+  u[0] = t[2] * X[1] - t[1] * X[2];
+  u[1] = t[0] * X[2] - t[2] * X[0];
+  u[2] = t[1] * X[0] - t[0] * X[1];
+  act_so3(qinv, u, v);
+  Y[3] += v[0];
+  Y[4] += v[1];
+  Y[5] += v[2];
+}
+
+// Tij = Tj * Ti^-1, dk:96-107; stereo pair (ix == jx): fixed baseline, dk:219-229
+template <bool STEREO = true>
+__device__ __forceinline__ Rel rel_pose(const float* __restrict__ poses, int ix, int jx) {
+  Rel r;
+  if (STEREO && ix == jx) {
+    r.t[0] = -0.1f; r.t[1] = 0.f; r.t[2] = 0.f;
+    r.q[0] = 0.f; r.q[1] = 0.f; r.q[2] = 0.f; r.q[3] = 1.f;
+    return r;
+  }
+  const float* pi = poses + 7 * (size_t)ix;
+  const float* pj = poses + 7 * (size_t)jx;
+  const float ti[3] = {pi[0], pi[1], pi[2]};
+  const float qi[4] = {pi[3], pi[4], pi[5], pi[6]};
+  const float tj[3] = {pj[0], pj[1], pj[2]};
+  const float qj[4] = {pj[3], pj[4], pj[5], pj[6]};
+  r.q[0] = -qj[3] * qi[0] + qj[0] * qi[3] - qj[1] * qi[2] + qj[2] * qi[1];
+  r.q[1] = -qj[3] * qi[1] + qj[1] * qi[3] - qj[2] * qi[0] + qj[0] * qi[2];
+  r.q[2] = -qj[3] * qi[2] + qj[2] * qi[3] - qj[0] * qi[1] + qj[1] * qi[0];
+  r.q[3] = qj[3] * qi[3] + qj[0] * qi[0] + qj[1] * qi[1] + qj[2] * qi[2];
+  float rt[3];
+  act_so3(r.q, ti, rt);
+  r.t[0] = tj[0] - rt[0];
+  r.t[1] = tj[1] - rt[1];
+  r.t[2] = tj[2] - rt[2];
+  return r;
+}
+
+// relSE3 without the stereo special case (projmap / frame_distance / depth_filter, dk:480, :582)
+__device__ __forceinline__ Rel rel_pose_plain(const float* __restrict__ poses, int ix, int jx) {
+  return rel_pose<false>(poses, ix, jx);
+}
+
+// Transform the back-projected pixel (u,v,disp) into frame j.  dk:290-296
+__device__ __forceinline__ void transform_pixel(const Intr& K, const Rel& T, float u, float v,
+                                                float disp, float* Xj) {
+  float Xi[3];
+  Xi[0] = (u - K.cx) / K.fx;
+  Xi[1] = (v - K.cy) / K.fy;
+  Xi[2] = 1.f;
+  act_so3(T.q, Xi, Xj);
+  Xj[3] = disp;
+  Xj[0] += disp * T.t[0];
+  Xj[1] += disp * T.t[1];
+  Xj[2] += disp * T.t[2];
+}
+
+// Per-pixel linearisation of one edge: both residual rows.  Jj rows have a structural zero each
+// (Jj_u[1] = 0, Jj_v[0] = 0; dk:313, :345).
+struct PixLin {
+  float Ju[6], Jv[6];  // d(proj)/d(xi_j), u and v rows                 dk:312-317, :345-350
+  float Jzu, Jzv;      // d(proj)/d(disp_i)                             dk:319, :352
+  float ru, rv;        // residuals target - proj                       dk:307-308
+  float valid;         // 0 when Z < MIN_DEPTH (weights are zeroed)     dk:302-306
+};
+
+__device__ __forceinline__ PixLin linearize_pixel(const Intr& K, const Rel& T, float u, float v,
+                                                  float disp, float tu, float tv) {
+  float Xj[4];
+  transform_pixel(K, T, u, v, disp, Xj);
+  const float x = Xj[0], y = Xj[1], h = Xj[3];
+  const bool bad = Xj[2] < DROID_MIN_DEPTH;
+  const float d = bad ? 0.f : 1.0f / Xj[2];
+  const float d2 = d * d;
+  PixLin L;
+  L.valid = bad ? 0.f : 1.f;
+  L.ru = tu - (K.fx * d * x + K.cx);
+  L.rv = tv - (K.fy * d * y + K.cy);
+  L.Ju[0] = K.fx * (h * d);
+  L.Ju[1] = 0.f;
+  L.Ju[2] = K.fx * (-x * h * d2);
+  L.Ju[3] = K.fx * (-x * y * d2);
+  L.Ju[4] = K.fx * (1.f + x * x * d2);
+  L.Ju[5] = K.fx * (-y * d);
+  L.Jzu = K.fx * (T.t[0] * d - T.t[2] * (x * d2));
+  L.Jv[0] = 0.f;
+  L.Jv[1] = K.fy * (h * d);
+  L.Jv[2] = K.fy * (-y * h * d2);
+  L.Jv[3] = K.fy * (-1.f - y * y * d2);
+  L.Jv[4] = K.fy * (x * y * d2);
+  L.Jv[5] = K.fy * (x * d);
+  L.Jzv = K.fy * (T.t[1] * d - T.t[2] * (y * d2));
+  return L;
+}
+
+// SO3 / SE3 exponential and the retraction T <- exp(xi) * T.  dk:110-175, :877-895
+__device__ __forceinline__ void exp_so3(const float* phi, float* q) {
+  float theta_sq = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+  float theta_p4 = theta_sq * theta_sq;
+  float theta = sqrtf(theta_sq);
+  float imag, real;
+  if (theta_sq < 1e-8f) {
+    imag = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_p4;
+    real = 1.0f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_p4;
+  } else {
+    imag = sinf(0.5f * theta) / theta;
+    real = cosf(0.5f * theta);
+  }
+  q[0] = imag * phi[0];
+  q[1] = imag * phi[1];
+  q[2] = imag * phi[2];
+  q[3] = real;
+}
+
+__device__ __forceinline__ void cross_inplace(const float* a, float* b) {
+  float x0 = a[1] * b[2] - a[2] * b[1];
+  float x1 = a[2] * b[0] - a[0] * b[2];
+  float x2 = a[0] * b[1] - a[1] * b[0];
+  b[0] = x0; b[1] = x1; b[2] = x2;
+}
+
+__device__ __forceinline__ void exp_se3(const float* xi, float* t, float* q) {
+  exp_so3(xi + 3, q);
+  float tau[3] = {xi[0], xi[1], xi[2]};
+  float phi[3] = {xi[3], xi[4], xi[5]};
+  float theta_sq = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+  float theta = sqrtf(theta_sq);
+  t[0] = tau[0]; t[1] = tau[1]; t[2] = tau[2];
+  if (theta > 1e-4f) {
+    float a = (1.f - cosf(theta)) / theta_sq;
+    cross_inplace(phi, tau);
+    t[0] += a * tau[0]; t[1] += a * tau[1]; t[2] += a * tau[2];
+    float b = (theta - sinf(theta)) / (theta * theta_sq);
+    cross_inplace(phi, tau);
+    t[0] += b * tau[0]; t[1] += b * tau[1]; t[2] += b * tau[2];
+  }
+}
+
+__device__ __forceinline__ void retr_se3(const float* xi, const float* t, const float* q, float* t1,
+                                         float* q1) {
+  float dt[3] = {0.f, 0.f, 0.f};
+  float dq[4] = {0.f, 0.f, 0.f, 1.f};
+  exp_se3(xi, dt, dq);
+  q1[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
+  q1[1] = dq[3] * q[1] + dq[1] * q[3] + dq[2] * q[0] - dq[0] * q[2];
+  q1[2] = dq[3] * q[2] + dq[2] * q[3] + dq[0] * q[1] - dq[1] * q[0];
+  q1[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
+  act_so3(dq, t, t1);
+  t1[0] += dt[0]; t1[1] += dt[1]; t1[2] += dt[2];
+}
+
+}  // namespace droid

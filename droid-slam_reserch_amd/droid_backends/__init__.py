@@ -1,0 +1,258 @@
+"""droid_backends -- MI355X (gfx950) drop-in for the reference's `droid_backends` extension.
+
+Same nine operators, argument order and return structure as the pybind module of
+/root/reference/src/droid.cpp:237-250, so `droid_slam/depth_video.py`, `factor_graph.py` and
+`modules/corr.py` import and call it unchanged on PyTorch-ROCm.  This file is the host-side
+mirror of droid.cpp: contiguity checks + thin calls into the C ABI
+(include/droid_backends_hip.h, libdroid_backends_hip.so) on PyTorch's current HIP stream.
+PyTorch is plumbing only (device memory, streams); all arithmetic is in the HIP library.
+"""
+from __future__ import annotations
+
+import os as _os
+
+import torch
+
+from . import _lib
+from ._lib import DroidBackendError  # noqa: F401
+
+__all__ = ["ba", "frame_distance", "projmap", "depth_filter", "iproj", "altcorr_forward",
+           "altcorr_backward", "corr_index_forward", "corr_index_backward"]
+
+_DT = {torch.float16: _lib.DROID_F16, torch.float32: _lib.DROID_F32, torch.float64: _lib.DROID_F64}
+_workspaces = {}
+
+# DROID_HIP_CHECK=1: read the BA status word back after every call (one sync) and raise on
+# contract violations; default: errors surface at the next call's check (no host sync at all).
+_SYNC_CHECK = _os.environ.get("DROID_HIP_CHECK", "0") == "1"
+
+
+def _check_input(x, name):
+    # CHECK_CONTIGUOUS, droid.cpp:84-85
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must be a HIP (cuda) tensor: droid_backends has no CPU path")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (kept across calls: no allocation on the hot path)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def ba_status(workspace=None):
+    """(status, depth_slots) of the last `ba` on the current device (blocking read)."""
+    import ctypes
+    lib = _lib.load()
+    if workspace is None:
+        workspace = _workspaces.get(torch.cuda.current_device())
+    if workspace is None:
+        return 0, 0
+    st, m = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.droid_ba_status(workspace.data_ptr(), _stream(), ctypes.byref(st), ctypes.byref(m)), "ba_status")
+    return st.value, m.value
+
+
+_STATUS_TEXT = {1: "edge index outside the pose buffer", 2: "eta rows != number of depth slots "
+                "|unique(ii) U [t0,t1)|", 4: "Cholesky failed (dx = 0)"}
+
+
+def _raise_on_status(st, m):
+    bad = [txt for bit, txt in _STATUS_TEXT.items() if (st & bit) and bit != 4]
+    if bad:
+        raise RuntimeError("droid_backends.ba: " + "; ".join(bad) + f" (device counted {m} depth slots)")
+
+
+def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations,
+       lm, ep, motion_only):
+    """Dense bundle adjustment, droid.cpp:88-117 -> ba_cuda droid_kernels.cu:1314-1434.
+
+    poses [nbuf,7] and disps [nbuf,H,W] are updated in place; returns [dx, dz] like the
+    reference (dz is an empty tensor when motion_only, where the reference returns an undefined
+    one).  eta is not contiguity-checked, as in the reference (droid.cpp:105-112), but it is
+    made contiguous here because the kernels index it directly.
+    """
+    lib = _lib.load()
+    for x, n in ((targets, "targets"), (weights, "weights"), (poses, "poses"), (disps, "disps"),
+                 (intrinsics, "intrinsics"), (disps_sens, "disps_sens"), (ii, "ii"), (jj, "jj")):
+        _check_input(x, n)
+    if ii.dtype != torch.int64 or jj.dtype != torch.int64:
+        raise RuntimeError("ii and jj must be int64")
+    for x, n in ((targets, "targets"), (weights, "weights"), (poses, "poses"), (disps, "disps"),
+                 (intrinsics, "intrinsics"), (disps_sens, "disps_sens")):
+        if x.dtype != torch.float32:
+            raise RuntimeError(f"{n} must be float32")
+    t0, t1, iterations = int(t0), int(t1), int(iterations)
+    motion_only = bool(motion_only)
+    nbuf, H, W = disps.shape
+    E = int(ii.shape[0])
+    P = t1 - t0
+    dev = poses.device
+    if motion_only:
+        M = 0
+        eta_c = None
+    else:
+        eta_c = eta.contiguous().to(torch.float32).view(-1, H * W)
+        M = int(eta_c.shape[0])
+    nbytes = lib.droid_ba_workspace_bytes(E, nbuf, H, W, t0, t1, M)
+    if nbytes == 0:
+        raise RuntimeError("droid_backends.ba: bad sizes / window")
+    ws = _workspace(nbytes, dev)
+    dx = torch.empty((max(P, 0), 6), dtype=torch.float32, device=dev)
+    dz = torch.empty((M, H * W), dtype=torch.float32, device=dev)
+    rc = lib.droid_ba(poses.data_ptr(), disps.data_ptr(), intrinsics.data_ptr(), disps_sens.data_ptr(),
+                      _ptr(targets), _ptr(weights), _ptr(eta_c), _ptr(ii), _ptr(jj), E, nbuf, H, W, M,
+                      t0, t1, iterations, float(lm), float(ep), int(motion_only), dx.data_ptr(),
+                      dz.data_ptr() if M > 0 else None, ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "ba")
+    if _SYNC_CHECK:
+        _raise_on_status(*ba_status(ws))
+    return [dx, dz]
+
+
+def frame_distance(poses, disps, intrinsics, ii, jj, beta):
+    """droid.cpp:120-136 -> frame_distance_cuda droid_kernels.cu:1438-1460."""
+    lib = _lib.load()
+    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
+        _check_input(x, n)
+    nbuf, H, W = disps.shape
+    nbuf = min(int(nbuf), int(poses.shape[0]))
+    E = int(ii.shape[0])
+    dist = torch.zeros((E,), dtype=torch.float32, device=poses.device)
+    _lib.check(lib.droid_frame_distance(poses.data_ptr(), disps.data_ptr(), intrinsics.data_ptr(),
+                                        ii.data_ptr(), jj.data_ptr(), E, nbuf, H, W, float(beta),
+                                        dist.data_ptr(), _stream()), "frame_distance")
+    return dist
+
+
+def projmap(poses, disps, intrinsics, ii, jj):
+    """droid.cpp:139-154 -> projmap_cuda droid_kernels.cu:1463-1488."""
+    lib = _lib.load()
+    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
+        _check_input(x, n)
+    nbuf, H, W = disps.shape
+    nbuf = min(int(nbuf), int(poses.shape[0]))
+    E = int(ii.shape[0])
+    coords = torch.empty((E, H, W, 3), dtype=torch.float32, device=poses.device)
+    valid = torch.empty((E, H, W, 1), dtype=torch.float32, device=poses.device)
+    _lib.check(lib.droid_projmap(poses.data_ptr(), disps.data_ptr(), intrinsics.data_ptr(), ii.data_ptr(),
+                                 jj.data_ptr(), E, nbuf, H, W, coords.data_ptr(), valid.data_ptr(),
+                                 _stream()), "projmap")
+    return [coords, valid]
+
+
+def depth_filter(poses, disps, intrinsics, ix, thresh):
+    """droid.cpp:220-234 -> depth_filter_cuda droid_kernels.cu:1491-1515."""
+    lib = _lib.load()
+    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ix, "ix"), (thresh, "thresh")):
+        _check_input(x, n)
+    nbuf, H, W = disps.shape
+    nbuf = min(int(nbuf), int(poses.shape[0]))
+    num = int(ix.shape[0])
+    counter = torch.empty((num, H, W), dtype=torch.float32, device=disps.device)
+    _lib.check(lib.droid_depth_filter(poses.data_ptr(), disps.data_ptr(), intrinsics.data_ptr(), ix.data_ptr(),
+                                      thresh.data_ptr(), num, nbuf, H, W, counter.data_ptr(), _stream()),
+               "depth_filter")
+    return counter
+
+
+def iproj(poses, disps, intrinsics):
+    """droid.cpp:157-166 -> iproj_cuda droid_kernels.cu:1518-1541."""
+    lib = _lib.load()
+    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics")):
+        _check_input(x, n)
+    nm, H, W = disps.shape
+    points = torch.empty((nm, H, W, 3), dtype=torch.float32, device=disps.device)
+    _lib.check(lib.droid_iproj(poses.data_ptr(), disps.data_ptr(), intrinsics.data_ptr(), nm, H, W,
+                               points.data_ptr(), _stream()), "iproj")
+    return points
+
+
+def _corr_dtype(t, name):
+    if t.dtype not in _DT:
+        raise RuntimeError(f"{name}: unsupported dtype {t.dtype} (float16/float32/float64)")
+    return _DT[t.dtype]
+
+
+def corr_index_forward(volume, coords, radius):
+    """droid.cpp:170-178 -> corr_index_cuda_forward correlation_kernels.cu:126-155."""
+    lib = _lib.load()
+    _check_input(volume, "volume")
+    _check_input(coords, "coords")
+    if coords.dtype != torch.float32:
+        raise RuntimeError("coords must be float32")
+    B, H1, W1, H2, W2 = volume.shape
+    r = int(radius)
+    corr = torch.empty((B, 2 * r + 1, 2 * r + 1, H1, W1), dtype=volume.dtype, device=volume.device)
+    _lib.check(lib.droid_corr_index_forward(volume.data_ptr(), coords.data_ptr(), corr.data_ptr(), B, H1, W1,
+                                            H2, W2, r, _corr_dtype(volume, "volume"), _stream()),
+               "corr_index_forward")
+    return [corr]
+
+
+def corr_index_backward(volume, coords, corr_grad, radius):
+    """droid.cpp:180-191 -> corr_index_cuda_backward correlation_kernels.cu:157-185."""
+    lib = _lib.load()
+    _check_input(volume, "volume")
+    _check_input(coords, "coords")
+    _check_input(corr_grad, "corr_grad")
+    B, H1, W1, H2, W2 = volume.shape
+    if corr_grad.dtype != volume.dtype:
+        corr_grad = corr_grad.to(volume.dtype)
+    volume_grad = torch.empty_like(volume)
+    _lib.check(lib.droid_corr_index_backward(coords.data_ptr(), corr_grad.data_ptr(), volume_grad.data_ptr(), B,
+                                             H1, W1, H2, W2, int(radius), _corr_dtype(volume, "volume"),
+                                             _stream()), "corr_index_backward")
+    return [volume_grad]
+
+
+def altcorr_forward(fmap1, fmap2, coords, radius):
+    """droid.cpp:193-203 -> altcorr_cuda_forward altcorr_kernel.cu:290-319."""
+    lib = _lib.load()
+    _check_input(fmap1, "fmap1")
+    _check_input(fmap2, "fmap2")
+    _check_input(coords, "coords")
+    if fmap2.dtype != fmap1.dtype or coords.dtype != torch.float32:
+        raise RuntimeError("altcorr_forward: fmap dtypes must match and coords must be float32")
+    B, N, H, W, _ = coords.shape
+    _, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    r = int(radius)
+    rd = 2 * r + 1
+    corr = torch.empty((B, N, rd * rd, H, W), dtype=fmap1.dtype, device=fmap1.device)
+    _lib.check(lib.droid_altcorr_forward(fmap1.data_ptr(), fmap2.data_ptr(), coords.data_ptr(), corr.data_ptr(),
+                                         B, N, H1, W1, H2, W2, C, r, _corr_dtype(fmap1, "fmap1"), _stream()),
+               "altcorr_forward")
+    return [corr]
+
+
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
+    """droid.cpp:205-217 -> altcorr_cuda_backward altcorr_kernel.cu:322-355 (fp32 only, like the reference)."""
+    lib = _lib.load()
+    for x, n in ((fmap1, "fmap1"), (fmap2, "fmap2"), (coords, "coords"), (corr_grad, "corr_grad")):
+        _check_input(x, n)
+        if x.dtype != torch.float32:
+            raise RuntimeError(f"altcorr_backward: {n} must be float32")
+    B, N, H, W, _ = coords.shape
+    _, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    fmap1_grad = torch.zeros_like(fmap1)
+    fmap2_grad = torch.zeros_like(fmap2)
+    coords_grad = torch.zeros_like(coords)
+    _lib.check(lib.droid_altcorr_backward(fmap1.data_ptr(), fmap2.data_ptr(), coords.data_ptr(),
+                                          corr_grad.data_ptr(), fmap1_grad.data_ptr(), fmap2_grad.data_ptr(),
+                                          B, N, H1, W1, H2, W2, C, int(radius), _stream()), "altcorr_backward")
+    return [fmap1_grad, fmap2_grad, coords_grad]

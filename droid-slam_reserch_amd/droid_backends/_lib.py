@@ -1,0 +1,80 @@
+"""ctypes binding of the C-ABI library (include/droid_backends_hip.h).
+
+The HIP library is the product: if it cannot be loaded this module raises -- there is no CPU
+fallback and nothing here imports the test oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdroid_backends_hip.so")
+
+# every symbol include/droid_backends_hip.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "droid_abi_version", "droid_last_error",
+    "droid_corr_index_forward", "droid_corr_index_backward",
+    "droid_altcorr_forward", "droid_altcorr_backward",
+    "droid_ba_workspace_bytes", "droid_ba", "droid_ba_prepare", "droid_ba_build",
+    "droid_ba_solve_update", "droid_ba_system", "droid_ba_status", "droid_chol_solve",
+    "droid_frame_distance", "droid_projmap", "droid_iproj", "droid_depth_filter",
+]
+
+DROID_F16, DROID_F32, DROID_F64 = 0, 1, 2
+
+_lib = None
+
+
+class DroidBackendError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libdroid_backends_hip.so (built by csrc/build.sh or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DroidBackendError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or droid-slam_reserch_amd/csrc/build.sh). "
+            "There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise DroidBackendError(f"{LIB_PATH} does not export {s}")
+    c_int, c_float, vp, sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+    lib.droid_abi_version.restype = c_int
+    lib.droid_last_error.restype = ctypes.c_char_p
+    lib.droid_corr_index_forward.argtypes = [vp, vp, vp] + [c_int] * 7 + [vp]
+    lib.droid_corr_index_backward.argtypes = [vp, vp, vp] + [c_int] * 7 + [vp]
+    lib.droid_altcorr_forward.argtypes = [vp, vp, vp, vp] + [c_int] * 9 + [vp]
+    lib.droid_altcorr_backward.argtypes = [vp] * 6 + [c_int] * 8 + [vp]
+    lib.droid_ba_workspace_bytes.argtypes = [c_int] * 7
+    lib.droid_ba_workspace_bytes.restype = sz
+    lib.droid_ba.argtypes = [vp] * 9 + [c_int] * 8 + [c_float, c_float, c_int, vp, vp, vp, sz, vp]
+    lib.droid_ba_prepare.argtypes = [vp, vp] + [c_int] * 10 + [vp, sz, vp]
+    lib.droid_ba_build.argtypes = [vp] * 9 + [c_int] * 8 + [vp, sz, vp]
+    lib.droid_ba_solve_update.argtypes = [vp] * 4 + [c_int] * 7 + [c_float, c_float, c_int, vp, vp, vp, sz, vp]
+    lib.droid_ba_system.argtypes = [vp] + [c_int] * 7 + [ctypes.POINTER(sz)]
+    lib.droid_ba_system.restype = vp
+    lib.droid_ba_status.argtypes = [vp, vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    lib.droid_chol_solve.argtypes = [vp, vp, vp, c_int, vp, vp, vp]
+    lib.droid_frame_distance.argtypes = [vp] * 5 + [c_int] * 4 + [c_float, vp, vp]
+    lib.droid_projmap.argtypes = [vp] * 5 + [c_int] * 4 + [vp, vp, vp]
+    lib.droid_iproj.argtypes = [vp] * 3 + [c_int] * 3 + [vp, vp]
+    lib.droid_depth_filter.argtypes = [vp] * 5 + [c_int] * 4 + [vp, vp]
+    for s in SYMBOLS[2:]:
+        if s not in ("droid_ba_workspace_bytes", "droid_ba_system"):
+            getattr(lib, s).restype = c_int
+    if lib.droid_abi_version() != 1:
+        raise DroidBackendError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().droid_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"droid_backends.{what} failed (rc={rc}): {msg}")

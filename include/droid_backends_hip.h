@@ -1,0 +1,157 @@
+/*
+ * droid_backends_hip.h -- C ABI of the MI355X (gfx950) implementation of DROID-SLAM's
+ * correlation-lookup + dense bundle-adjustment hot path.
+ *
+ * This is the drop-in boundary: one entry point per operator the reference exports from its
+ * `droid_backends` pybind module (/root/reference/src/droid.cpp:237-250).  Signatures carry only
+ * raw DEVICE pointers, sizes and a HIP stream (passed as void*, a hipStream_t); no torch types.
+ * Every function enqueues on `stream` and returns without synchronising unless stated.
+ *
+ * Return value: 0 on success, a negative DROID_E_* code on a contract violation detected on the
+ * host.  Violations only a kernel can see (index out of range, eta rows != depth slots) are
+ * written to the status word in the BA workspace (see droid_ba_status).
+ *
+ * Tensor layouts are exactly the reference's (row-major, contiguous):
+ *   poses  [nbuf,7]  f32  (tx ty tz qx qy qz qw), world->camera     depth_video.py:33
+ *   disps  [nbuf,H,W] f32 ; disps_sens [nbuf,H,W] f32 ; intrinsics [4] f32 (fx fy cx cy)
+ *   targets, weights [E,2,H,W] f32 ; eta [M,H,W] f32 ; ii, jj [E] int64
+ */
+#ifndef DROID_BACKENDS_HIP_H
+#define DROID_BACKENDS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DROID_ABI_VERSION 1
+
+#define DROID_OK 0
+#define DROID_E_ARG (-1)       /* bad size / null pointer / unsupported dtype            */
+#define DROID_E_WORKSPACE (-2) /* workspace too small                                    */
+#define DROID_E_HIP (-3)       /* a HIP runtime call failed (see droid_last_error)       */
+
+/* element types of the correlation operators (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * correlation_kernels.cu:145, altcorr_kernel.cu:308) */
+#define DROID_F16 0
+#define DROID_F32 1
+#define DROID_F64 2
+
+int droid_abi_version(void);
+const char *droid_last_error(void); /* thread-local message of the last failing call */
+
+/* ------------------------------------------------------------------ correlation lookups */
+
+/* corr_index_forward (droid.cpp:170-178 -> correlation_kernels.cu:126-155).
+ * volume [B,H1,W1,H2,W2] dtype ; coords [B,2,H1,W1] f32 ; corr [B,2r+1,2r+1,H1,W1] dtype
+ * (written completely; the caller need not zero it). */
+int droid_corr_index_forward(const void *volume, const float *coords, void *corr, int B, int H1,
+                             int W1, int H2, int W2, int radius, int dtype, void *stream);
+
+/* corr_index_backward (droid.cpp:180-191 -> correlation_kernels.cu:157-185).
+ * corr_grad [B,2r+1,2r+1,H1,W1] dtype ; volume_grad [B,H1,W1,H2,W2] dtype (written completely). */
+int droid_corr_index_backward(const float *coords, const void *corr_grad, void *volume_grad, int B,
+                              int H1, int W1, int H2, int W2, int radius, int dtype, void *stream);
+
+/* altcorr_forward (droid.cpp:193-203 -> altcorr_kernel.cu:290-319).
+ * fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] dtype ; coords [B,N,H1,W1,2] f32 ;
+ * corr [B,N,(2r+1)^2,H1,W1] dtype, channel = ix*(2r+1)+iy (written completely). */
+int droid_altcorr_forward(const void *fmap1, const void *fmap2, const float *coords, void *corr,
+                          int B, int N, int H1, int W1, int H2, int W2, int C, int radius,
+                          int dtype, void *stream);
+
+/* altcorr_backward (droid.cpp:205-217 -> altcorr_kernel.cu:322-355), fp32 only like the reference.
+ * fmap1_grad/fmap2_grad must be zero-filled by the caller (atomic accumulation);
+ * coords_grad is not written (the reference returns zeros). */
+int droid_altcorr_backward(const float *fmap1, const float *fmap2, const float *coords,
+                           const float *corr_grad, float *fmap1_grad, float *fmap2_grad, int B,
+                           int N, int H1, int W1, int H2, int W2, int C, int radius, void *stream);
+
+/* ------------------------------------------------------------------ bundle adjustment */
+
+/* Bytes of device scratch one `ba` call needs (host-only arithmetic, no HIP call).
+ * M = rows of eta = number of depth slots |unique(ii) U [t0,t1)| (0 when motion_only). */
+size_t droid_ba_workspace_bytes(int E, int nbuf, int H, int W, int t0, int t1, int M);
+
+/* ba (droid.cpp:88-117 -> droid_kernels.cu:1314-1434): `iterations` Gauss-Newton steps, poses
+ * and disps updated in place.  dx_out [t1-t0,6] f32 and dz_out [M,H*W] f32 receive the last
+ * iteration's updates (dz_out may be NULL when motion_only).  Equivalent to
+ * droid_ba_prepare + iterations x (droid_ba_build, droid_ba_solve_update). */
+int droid_ba(float *poses, float *disps, const float *intrinsics, const float *disps_sens,
+             const float *targets, const float *weights, const float *eta, const int64_t *ii,
+             const int64_t *jj, int E, int nbuf, int H, int W, int M, int t0, int t1,
+             int iterations, float lm, float ep, int motion_only, float *dx_out, float *dz_out,
+             void *workspace, size_t workspace_bytes, void *stream);
+
+/* Phase API (what the multi-GPU driver calls; single-GPU `droid_ba` is built from it).
+ *
+ * own0/own1: the frames whose depth maps this rank owns.  Edges passed to a rank must all have
+ * ii in [own0,own1); window frames outside it create no depth slot here.  Single GPU: 0, nbuf.
+ *
+ * droid_ba_prepare: once per call -- depth-slot table, CSR of edges by source frame.
+ * droid_ba_build:   one linearisation: writes this rank's contribution to the reduced camera
+ *                   system into the workspace: S = [ A - E C^-1 E^T | . ; b^T | . ] as a dense
+ *                   (6P+1) x (6P+1) fp64 row-major matrix, lower triangle valid, row 6P = rhs,
+ *                   no damping yet.  droid_ba_system() returns its device address so that the
+ *                   caller can all-reduce (sum) it over ranks (RCCL) before the solve.
+ * droid_ba_solve_update: damping (diag += ep + lm*diag), Cholesky, solve, depth
+ *                   back-substitution for the owned slots, SE3 / disparity retraction.
+ */
+int droid_ba_prepare(const int64_t *ii, const int64_t *jj, int E, int nbuf, int H, int W, int M,
+                     int t0, int t1, int own0, int own1, int motion_only, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
+int droid_ba_build(const float *poses, const float *disps, const float *intrinsics,
+                   const float *disps_sens, const float *targets, const float *weights,
+                   const float *eta, const int64_t *ii, const int64_t *jj, int E, int nbuf, int H,
+                   int W, int M, int t0, int t1, int motion_only, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+int droid_ba_solve_update(float *poses, float *disps, const int64_t *ii, const int64_t *jj, int E,
+                          int nbuf, int H, int W, int M, int t0, int t1, float lm, float ep,
+                          int motion_only, float *dx_out, float *dz_out, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
+/* Device address / element count of the dense fp64 system inside the workspace. */
+double *droid_ba_system(void *workspace, int E, int nbuf, int H, int W, int t0, int t1, int M,
+                        size_t *n_elements);
+
+/* Blocking read of the workspace status word: 0 ok; bit0 index out of range; bit1 eta rows !=
+ * depth slots; bit2 Cholesky failed in the last solve (dx = 0, like droid_kernels.cu:1207-1210). */
+int droid_ba_status(const void *workspace, void *stream, int *status_out, int *depth_slots_out);
+
+/* Dense SPD solve used by the BA (exposed for tests): A [n,n] fp64 row-major (lower triangle
+ * read, destroyed), b [n] fp64 -> x [n] fp64.  fail_flag (device int) is set to 1 when a pivot
+ * is not positive.  scratch: >= (n+1)*(n+1) doubles. */
+int droid_chol_solve(const double *A, const double *b, double *x, int n, double *scratch,
+                     int *fail_flag, void *stream);
+
+/* ------------------------------------------------------------------ geometry operators */
+
+/* frame_distance (droid.cpp:120-136 -> droid_kernels.cu:518-657, :1438-1460): dist [E] f32 */
+int droid_frame_distance(const float *poses, const float *disps, const float *intrinsics,
+                         const int64_t *ii, const int64_t *jj, int E, int nbuf, int H, int W,
+                         float beta, float *dist, void *stream);
+
+/* projmap (droid.cpp:139-154 -> droid_kernels.cu:427-516, :1463-1488):
+ * coords [E,H,W,3] f32 (channel 2 zero), valid [E,H,W,1] f32 */
+int droid_projmap(const float *poses, const float *disps, const float *intrinsics,
+                  const int64_t *ii, const int64_t *jj, int E, int nbuf, int H, int W,
+                  float *coords, float *valid, void *stream);
+
+/* iproj (droid.cpp:157-166 -> droid_kernels.cu:779-850, :1518-1541): points [nm,H,W,3] f32 */
+int droid_iproj(const float *poses, const float *disps, const float *intrinsics, int nm, int H,
+                int W, float *points, void *stream);
+
+/* depth_filter (droid.cpp:220-234 -> droid_kernels.cu:661-775, :1491-1515):
+ * counter [num,H,W] f32 (written completely) */
+int droid_depth_filter(const float *poses, const float *disps, const float *intrinsics,
+                       const int64_t *ix, const float *thresh, int num, int nbuf, int H, int W,
+                       float *counter, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DROID_BACKENDS_HIP_H */
