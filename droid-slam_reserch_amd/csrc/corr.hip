@@ -16,6 +16,11 @@
 
 #include "../../include/droid_backends_hip.h"
 
+// The rounding points are part of the contract: no fused multiply-add and no mixed-precision
+// folding (hipcc's default -ffp-contract=fast turns round_f16(a*b) into v_fma_mixlo_f16, which
+// rounds once instead of f32-then-f16 like the reference's `scalar_t(dx * dy)`).
+#pragma clang fp contract(off)
+
 namespace droid {
 
 // ---- element-type arithmetic with the reference's rounding points -------------------------
@@ -44,6 +49,14 @@ template <> struct Elem<double> {
   static __device__ __forceinline__ double mul(double a, double b) { return __dmul_rn(a, b); }
   static __device__ __forceinline__ double add(double a, double b) { return __dadd_rn(a, b); }
 };
+
+// Keeps an fp32 product as a real fp32 value: without it the backend folds
+// round_f16(a * b) into v_fma_mixlo_f16, which rounds the exact product once (measured on
+// gfx950: differs from the reference's f32-multiply-then-convert in ~1e-4 of the weights).
+__device__ __forceinline__ float f32_value(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 
 struct Bilin {
   int x1, y1;       // top-left integer tap = floor(coord) - r
@@ -96,10 +109,10 @@ __global__ __launch_bounds__(256) void corr_index_forward_kernel(const T* __rest
   }
   const float one = 1.0f;
   // weights rounded to the element type (ck:55-65)
-  const work w00 = Elem<T>::round((work)((one - bl.dx) * (one - bl.dy)));  // tap (a  ,c  )
-  const work w01 = Elem<T>::round((work)((one - bl.dx) * bl.dy));          // tap (a  ,c+1)
-  const work w10 = Elem<T>::round((work)(bl.dx * (one - bl.dy)));          // tap (a+1,c  )
-  const work w11 = Elem<T>::round((work)(bl.dx * bl.dy));                  // tap (a+1,c+1)
+  const work w00 = Elem<T>::round((work)f32_value((one - bl.dx) * (one - bl.dy)));  // tap (a  ,c  )
+  const work w01 = Elem<T>::round((work)f32_value((one - bl.dx) * bl.dy));          // tap (a  ,c+1)
+  const work w10 = Elem<T>::round((work)f32_value(bl.dx * (one - bl.dy)));          // tap (a+1,c  )
+  const work w11 = Elem<T>::round((work)f32_value(bl.dx * bl.dy));                  // tap (a+1,c+1)
   T* out = corr + (size_t)b * RD * RD * H1W1 + pix;
 #pragma unroll
   for (int a = 0; a < RD; a++) {
@@ -133,10 +146,10 @@ __global__ __launch_bounds__(256) void corr_index_forward_generic(const T* __res
     if (x1 < 0 || x1 >= W2 || y1 < 0 || y1 >= H2) return (work)0;
     return Elem<T>::load(plane + (size_t)y1 * W2 + x1);
   };
-  const work w00 = Elem<T>::round((work)((1.0f - bl.dx) * (1.0f - bl.dy)));
-  const work w01 = Elem<T>::round((work)((1.0f - bl.dx) * bl.dy));
-  const work w10 = Elem<T>::round((work)(bl.dx * (1.0f - bl.dy)));
-  const work w11 = Elem<T>::round((work)(bl.dx * bl.dy));
+  const work w00 = Elem<T>::round((work)f32_value((1.0f - bl.dx) * (1.0f - bl.dy)));
+  const work w01 = Elem<T>::round((work)f32_value((1.0f - bl.dx) * bl.dy));
+  const work w10 = Elem<T>::round((work)f32_value(bl.dx * (1.0f - bl.dy)));
+  const work w11 = Elem<T>::round((work)f32_value(bl.dx * bl.dy));
   T* out = corr + (size_t)b * rd * rd * H1W1 + pix;
   for (int a = 0; a < rd; a++)
     for (int c = 0; c < rd; c++) {
@@ -190,10 +203,10 @@ __global__ __launch_bounds__(256) void corr_index_backward_kernel(const float* _
                                coords[((size_t)b * 2 + 1) * H1W1 + pix], r);
   T* plane = volume_grad + ((size_t)b * H1W1 + pix) * ((size_t)H2 * W2);
   const T* g = corr_grad + (size_t)b * rd * rd * H1W1 + pix;
-  const work w11 = Elem<T>::round((work)(bl.dx * bl.dy));
-  const work w10 = Elem<T>::round((work)(bl.dx * (1.0f - bl.dy)));
-  const work w01 = Elem<T>::round((work)((1.0f - bl.dx) * bl.dy));
-  const work w00 = Elem<T>::round((work)((1.0f - bl.dx) * (1.0f - bl.dy)));
+  const work w11 = Elem<T>::round((work)f32_value(bl.dx * bl.dy));
+  const work w10 = Elem<T>::round((work)f32_value(bl.dx * (1.0f - bl.dy)));
+  const work w01 = Elem<T>::round((work)f32_value((1.0f - bl.dx) * bl.dy));
+  const work w00 = Elem<T>::round((work)f32_value((1.0f - bl.dx) * (1.0f - bl.dy)));
   for (int i = 0; i < rd + 1; i++)
     for (int j = 0; j < rd + 1; j++) {
       const int x1 = bl.x1 + i, y1 = bl.y1 + j;
@@ -256,10 +269,10 @@ __global__ __launch_bounds__(256) void altcorr_forward_generic(const T* __restri
   const T* f1 = fmap1 + ((size_t)b * H1W1 + pix) * C;
   const T* f2b = fmap2 + (size_t)b * H2 * W2 * C;
   T* out = corr + (((size_t)b * N + n) * rd * rd) * H1W1 + pix;
-  const work wnw = Elem<T>::round((work)(bl.dy * bl.dx));                  // ak:119-122
-  const work wne = Elem<T>::round((work)(bl.dy * (1.0f - bl.dx)));
-  const work wsw = Elem<T>::round((work)((1.0f - bl.dy) * bl.dx));
-  const work wse = Elem<T>::round((work)((1.0f - bl.dy) * (1.0f - bl.dx)));
+  const work wnw = Elem<T>::round((work)f32_value(bl.dy * bl.dx));                  // ak:119-122
+  const work wne = Elem<T>::round((work)f32_value(bl.dy * (1.0f - bl.dx)));
+  const work wsw = Elem<T>::round((work)f32_value((1.0f - bl.dy) * bl.dx));
+  const work wse = Elem<T>::round((work)f32_value((1.0f - bl.dy) * (1.0f - bl.dx)));
   // dot products of the (rd+1)^2 taps, one row of taps at a time, two rows live
   for (int ox = 0; ox < rd; ox++) {
     for (int oy = 0; oy < rd; oy++) {
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(256) void altcorr_forward_generic(const T* __restri
         work s = (work)0;
         if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
           const T* f2 = f2b + ((size_t)h2 * W2 + w2) * C;
-          for (int c = sub; c < C; c += 16) s += (work)Elem<T>::load(f1 + c) * (work)Elem<T>::load(f2 + c);
+          for (int c = sub; c < C; c += 16) s = fma((work)Elem<T>::load(f1 + c), (work)Elem<T>::load(f2 + c), s);
         }
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);

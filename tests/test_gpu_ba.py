@@ -192,3 +192,16 @@ def test_ba_zero_weight_edges_change_nothing(backends, synth):
     b = run_hip_ba(backends, q, torch, 2)
     assert np.abs(a["poses"] - b["poses"]).max() < 1e-6
     assert np.abs(a["disps"] - b["disps"]).max() < 1e-5
+
+
+def test_ba_golden_vectors_on_device(backends, synth):
+    """Committed fixtures (tests/golden/ba_golden.npz): device state after 2 iterations vs stored."""
+    import os
+    torch = _torch()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_golden.npz"))
+    cases = {"tiny": synth.make_ba_problem(N=3, E=4, H=16, W=24, seed=11), "cfg1": synth.make_config("cfg1"),
+             "cfg1_rgbd": synth.make_config("cfg1", rgbd=True, seed=21)}
+    for name, p in cases.items():
+        hip = run_hip_ba(backends, p, torch, 2)
+        assert np.abs(hip["poses"] - g[f"{name}_poses"]).max() < TOL
+        assert np.abs(hip["disps"] - g[f"{name}_disps"]).max() < TOL

@@ -135,3 +135,18 @@ def test_altcorr_multi_coordinate_sets_and_radius4(backends, oracle):
     out, = backends.altcorr_forward(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(),
                                     torch.from_numpy(coords).cuda(), 4)
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+
+
+def test_corr_golden_vectors_on_device(backends):
+    """Committed fixtures (tests/golden/corr_golden.npz): device output vs stored expected output."""
+    import os
+    torch = _torch()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "corr_golden.npz"))
+    c = torch.from_numpy(g["coords"]).cuda()
+    out16, = backends.corr_index_forward(torch.from_numpy(g["volume"]).cuda(), c, 3)
+    assert np.array_equal(out16.cpu().numpy(), g["corr_f16"])
+    out32, = backends.corr_index_forward(torch.from_numpy(g["volume"].astype(np.float32)).cuda(), c, 3)
+    assert np.array_equal(out32.cpu().numpy(), g["corr_f32"])
+    alt, = backends.altcorr_forward(torch.from_numpy(g["fmap1"]).cuda(), torch.from_numpy(g["fmap2"]).cuda(),
+                                    torch.from_numpy(g["alt_coords"]).cuda(), 3)
+    assert np.abs(alt.cpu().numpy() - g["altcorr"]).max() < 1e-5 * np.abs(g["altcorr"]).max()
