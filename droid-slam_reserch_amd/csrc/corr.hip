@@ -30,24 +30,24 @@ template <> struct Elem<__half> {
   static __device__ __forceinline__ float load(const __half* p) { return __half2float(*p); }
   static __device__ __forceinline__ float round(float x) { return __half2float(__float2half_rn(x)); }
   static __device__ __forceinline__ void store(__half* p, float x) { *p = __float2half_rn(x); }
-  static __device__ __forceinline__ float mul(float a, float b) { return round(__fmul_rn(a, b)); }
-  static __device__ __forceinline__ float add(float a, float b) { return round(__fadd_rn(a, b)); }
+  static __device__ __forceinline__ float mul(float a, float b) { return round(a * b); }
+  static __device__ __forceinline__ float add(float a, float b) { return round(a + b); }
 };
 template <> struct Elem<float> {
   typedef float work;
   static __device__ __forceinline__ float load(const float* p) { return *p; }
   static __device__ __forceinline__ float round(float x) { return x; }
   static __device__ __forceinline__ void store(float* p, float x) { *p = x; }
-  static __device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
-  static __device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
+  static __device__ __forceinline__ float mul(float a, float b) { return a * b; }
+  static __device__ __forceinline__ float add(float a, float b) { return a + b; }
 };
 template <> struct Elem<double> {
   typedef double work;
   static __device__ __forceinline__ double load(const double* p) { return *p; }
   static __device__ __forceinline__ double round(double x) { return x; }
   static __device__ __forceinline__ void store(double* p, double x) { *p = x; }
-  static __device__ __forceinline__ double mul(double a, double b) { return __dmul_rn(a, b); }
-  static __device__ __forceinline__ double add(double a, double b) { return __dadd_rn(a, b); }
+  static __device__ __forceinline__ double mul(double a, double b) { return a * b; }
+  static __device__ __forceinline__ double add(double a, double b) { return a + b; }
 };
 
 // Keeps an fp32 product as a real fp32 value: without it the backend folds
