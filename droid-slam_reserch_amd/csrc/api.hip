@@ -180,7 +180,7 @@ int droid_ba_solve_update(float* poses, float* disps, const int64_t* ii, const i
   if (rc) return rc;
   if (!poses || !disps) return fail(DROID_E_ARG, "ba: null %s", "state pointer");
   hipStream_t s = (hipStream_t)stream;
-  hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
+  (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
   launch_chol_solve(v.sys, v.n, v.ld, (double)lm, (double)ep, v.xsol, v.hdr + HDR_CHOL_FAIL, s);
   launch_update(v, poses, disps, v.xsol, dx_out, dz_out, motion_only != 0, s);
   return check_hip("ba_solve_update");
@@ -203,6 +203,49 @@ int droid_ba(float* poses, float* disps, const float* intrinsics, const float* d
     if (rc) return rc;
   }
   return DROID_OK;
+}
+
+// Measurement support: one Gauss-Newton iteration (after droid_ba_prepare) with a HIP event
+// between kernel groups on `stream`; blocks until done.  stage_ms[8] = {memset+linearise,
+// assemble, schur SYRK, rhs Ev, damp+factor, back-substitution solve, dx/disps/poses update, total}.
+int droid_ba_profile_iteration(float* poses, float* disps, const float* intrinsics,
+                               const float* disps_sens, const float* targets, const float* weights,
+                               const float* eta, const int64_t* ii, const int64_t* jj, int E,
+                               int nbuf, int H, int W, int M, int t0, int t1, float lm, float ep,
+                               int motion_only, void* workspace, size_t workspace_bytes,
+                               void* stream, float* stage_ms) {
+  BaView v;
+  int rc = ba_view(v, workspace, workspace_bytes, E, nbuf, H, W, t0, t1, M, motion_only);
+  if (rc) return rc;
+  if (!stage_ms) return fail(DROID_E_ARG, "ba_profile: null %s", "stage_ms");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t ev[8];
+  for (auto& e : ev) (void)hipEventCreate(&e);
+  (void)hipEventRecord(ev[0], s);
+  launch_build_stage(v, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, motion_only != 0, 0, s);
+  (void)hipEventRecord(ev[1], s);
+  launch_build_stage(v, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, motion_only != 0, 1, s);
+  (void)hipEventRecord(ev[2], s);
+  launch_build_stage(v, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, motion_only != 0, 2, s);
+  (void)hipEventRecord(ev[3], s);
+  launch_build_stage(v, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, motion_only != 0, 3, s);
+  (void)hipEventRecord(ev[4], s);
+  (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
+  launch_chol_factor(v.sys, v.n, v.ld, (double)lm, (double)ep, v.hdr + HDR_CHOL_FAIL, s);
+  (void)hipEventRecord(ev[5], s);
+  launch_chol_backsolve(v.sys, v.n, v.ld, v.xsol, s);
+  (void)hipEventRecord(ev[6], s);
+  launch_update(v, poses, disps, v.xsol, nullptr, nullptr, motion_only != 0, s);
+  (void)hipEventRecord(ev[7], s);
+  hipError_t e = hipEventSynchronize(ev[7]);
+  for (int k = 0; k < 7; k++) (void)hipEventElapsedTime(&stage_ms[k], ev[k], ev[k + 1]);
+  (void)hipEventElapsedTime(&stage_ms[7], ev[0], ev[7]);
+  for (auto& x : ev) (void)hipEventDestroy(x);
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "ba_profile: %s", hipGetErrorString(e));
+    return DROID_E_HIP;
+  }
+  return check_hip("ba_profile_iteration");
 }
 
 double* droid_ba_system(void* workspace, int E, int nbuf, int H, int W, int t0, int t1, int M,
@@ -233,7 +276,7 @@ int droid_chol_solve(const double* A, const double* b, double* x, int n, double*
   if (n <= 0 || !A || !b || !x || !scratch || !fail_flag) return fail(DROID_E_ARG, "chol_solve: bad %s", "argument");
   hipStream_t s = (hipStream_t)stream;
   const int ld = n + 1;
-  hipMemsetAsync(fail_flag, 0, sizeof(int), s);
+  (void)hipMemsetAsync(fail_flag, 0, sizeof(int), s);
   launch_chol_pack(A, b, scratch, n, ld, s);
   launch_chol_solve(scratch, n, ld, 0.0, 0.0, x, fail_flag, s);
   return check_hip("chol_solve");

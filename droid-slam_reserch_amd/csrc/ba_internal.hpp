@@ -86,10 +86,19 @@ void launch_prep(const BaView& v, const int64_t* ii, const int64_t* jj, hipStrea
 void launch_build(const BaView& v, const float* poses, const float* disps, const float* intr,
                   const float* sens, const float* targets, const float* weights, const float* eta,
                   const int64_t* ii, const int64_t* jj, bool motion_only, hipStream_t s);
+// stage: 0 memset+linearise, 1 assemble, 2 schur, 3 ev (measurement support)
+void launch_build_stage(const BaView& v, const float* poses, const float* disps, const float* intr,
+                        const float* sens, const float* targets, const float* weights,
+                        const float* eta, const int64_t* ii, const int64_t* jj, bool motion_only,
+                        int stage, hipStream_t s);
 void launch_update(const BaView& v, float* poses, float* disps, const double* x, float* dx_out,
                    float* dz_out, bool motion_only, hipStream_t s);
 // In-place damped Cholesky of the lower triangle of sys (ld x ld, row n = rhs) + solve -> x [n].
 void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
                        hipStream_t s);
+
+void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag,
+                        hipStream_t s);
+void launch_chol_backsolve(double* sys, int n, int ld, double* x, hipStream_t s);
 
 }  // namespace droid

@@ -631,27 +631,39 @@ void launch_prep(const BaView& v, const int64_t* ii, const int64_t* jj, hipStrea
   hipLaunchKernelGGL(ba_prep_kernel, dim3(1), dim3(1024), 0, s, v, ii, jj);
 }
 
+void launch_build_stage(const BaView& v, const float* poses, const float* disps, const float* intr,
+                        const float* sens, const float* targets, const float* weights,
+                        const float* eta, const int64_t* ii, const int64_t* jj, bool motion_only,
+                        int stage, hipStream_t s) {
+  const bool depth = !motion_only && v.M > 0;
+  switch (stage) {
+    case 0:
+      (void)hipMemsetAsync(v.sys, 0, sizeof(double) * (size_t)v.ld * v.ld, s);
+      if (depth)
+        hipLaunchKernelGGL(ba_lin_kernel<true>, dim3(v.M, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
+                           disps, intr, sens, targets, weights, eta, ii, jj);
+      else if (v.E > 0)
+        hipLaunchKernelGGL(ba_lin_kernel<false>, dim3(v.E, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
+                           disps, intr, sens, targets, weights, eta, ii, jj);
+      break;
+    case 1:
+      if (v.E > 0)
+        hipLaunchKernelGGL(ba_assemble_kernel, dim3(v.E), dim3(64), 0, s, v, poses, ii, jj);
+      break;
+    case 2:
+      if (depth) hipLaunchKernelGGL(ba_schur_kernel, dim3(SCHUR_GRID), dim3(256), 0, s, v);
+      break;
+    case 3:
+      if (depth) hipLaunchKernelGGL(ba_ev_kernel, dim3(1024), dim3(256), 0, s, v);
+      break;
+  }
+}
+
 void launch_build(const BaView& v, const float* poses, const float* disps, const float* intr,
                   const float* sens, const float* targets, const float* weights, const float* eta,
                   const int64_t* ii, const int64_t* jj, bool motion_only, hipStream_t s) {
-  hipMemsetAsync(v.sys, 0, sizeof(double) * (size_t)v.ld * v.ld, s);
-  if (v.E > 0) {
-    if (motion_only) {
-      hipLaunchKernelGGL(ba_lin_kernel<false>, dim3(v.E, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
-                         disps, intr, sens, targets, weights, eta, ii, jj);
-    } else {
-      hipLaunchKernelGGL(ba_lin_kernel<true>, dim3(v.M, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
-                         disps, intr, sens, targets, weights, eta, ii, jj);
-    }
-    hipLaunchKernelGGL(ba_assemble_kernel, dim3(v.E), dim3(64), 0, s, v, poses, ii, jj);
-  } else if (!motion_only && v.M > 0) {
-    hipLaunchKernelGGL(ba_lin_kernel<true>, dim3(v.M, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
-                       disps, intr, sens, targets, weights, eta, ii, jj);
-  }
-  if (!motion_only && v.M > 0) {
-    hipLaunchKernelGGL(ba_schur_kernel, dim3(SCHUR_GRID), dim3(256), 0, s, v);
-    hipLaunchKernelGGL(ba_ev_kernel, dim3(1024), dim3(256), 0, s, v);
-  }
+  for (int stage = 0; stage < 4; stage++)
+    launch_build_stage(v, poses, disps, intr, sens, targets, weights, eta, ii, jj, motion_only, stage, s);
 }
 
 void launch_update(const BaView& v, float* poses, float* disps, const double* x, float* dx_out,

@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(double* __restrict_
   }
 }
 
-void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
-                       hipStream_t s) {
+void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag,
+                        hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(chol_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sys, n, ld, lm, ep);
   const int nb = (n + NB - 1) / NB;
@@ -197,11 +197,22 @@ void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double*
       hipLaunchKernelGGL(chol_update_kernel, dim3(nrb - k - 1, nb - k - 1), dim3(256), 0, s, sys, n,
                          ld, k);
   }
+}
+
+void launch_chol_backsolve(double* sys, int n, int ld, double* x, hipStream_t s) {
+  const int nb = (n + NB - 1) / NB;
   for (int k = nb - 1; k >= 0; k--) {
     const int c0 = k * NB;
     hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1 + (c0 + 255) / 256), dim3(256), 0, s, sys, n,
                        ld, k, x);
   }
+}
+
+void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
+                       hipStream_t s) {
+  if (n <= 0) return;
+  launch_chol_factor(sys, n, ld, lm, ep, fail_flag, s);
+  launch_chol_backsolve(sys, n, ld, x, s);
 }
 
 // helper for droid_chol_solve: pack (A, b) into the augmented layout

@@ -228,7 +228,7 @@ template <typename T>
 static int corr_index_backward_t(const float* coords, const void* corr_grad, void* volume_grad,
                                  int B, int H1, int W1, int H2, int W2, int r, hipStream_t s) {
   const int HW = H1 * W1;
-  hipMemsetAsync(volume_grad, 0, sizeof(T) * (size_t)B * HW * H2 * W2, s);
+  (void)hipMemsetAsync(volume_grad, 0, sizeof(T) * (size_t)B * HW * H2 * W2, s);
   hipLaunchKernelGGL((corr_index_backward_kernel<T>), dim3((HW + 255) / 256, B), dim3(256), 0, s,
                      coords, static_cast<const T*>(corr_grad), static_cast<T*>(volume_grad), HW, H2,
                      W2, r);

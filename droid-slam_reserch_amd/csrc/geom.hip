@@ -176,8 +176,8 @@ void launch_frame_distance(const float* poses, const float* disps, const float* 
 void launch_projmap(const float* poses, const float* disps, const float* intr, const int64_t* ii,
                     const int64_t* jj, int E, int nbuf, int H, int W, float* coords, float* valid,
                     hipStream_t s) {
-  hipMemsetAsync(coords, 0, sizeof(float) * (size_t)E * H * W * 3, s);
-  hipMemsetAsync(valid, 0, sizeof(float) * (size_t)E * H * W, s);
+  (void)hipMemsetAsync(coords, 0, sizeof(float) * (size_t)E * H * W * 3, s);
+  (void)hipMemsetAsync(valid, 0, sizeof(float) * (size_t)E * H * W, s);
   hipLaunchKernelGGL(projmap_kernel, dim3((H * W + 255) / 256, E), dim3(256), 0, s, poses, disps,
                      intr, ii, jj, coords, valid, nbuf, H, W);
 }

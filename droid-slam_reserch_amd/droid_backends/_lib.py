@@ -17,7 +17,7 @@ SYMBOLS = [
     "droid_corr_index_forward", "droid_corr_index_backward",
     "droid_altcorr_forward", "droid_altcorr_backward",
     "droid_ba_workspace_bytes", "droid_ba", "droid_ba_prepare", "droid_ba_build",
-    "droid_ba_solve_update", "droid_ba_system", "droid_ba_status", "droid_chol_solve",
+    "droid_ba_solve_update", "droid_ba_profile_iteration", "droid_ba_system", "droid_ba_status", "droid_chol_solve",
     "droid_frame_distance", "droid_projmap", "droid_iproj", "droid_depth_filter",
 ]
 
@@ -57,6 +57,7 @@ def load() -> ctypes.CDLL:
     lib.droid_ba_prepare.argtypes = [vp, vp] + [c_int] * 10 + [vp, sz, vp]
     lib.droid_ba_build.argtypes = [vp] * 9 + [c_int] * 8 + [vp, sz, vp]
     lib.droid_ba_solve_update.argtypes = [vp] * 4 + [c_int] * 7 + [c_float, c_float, c_int, vp, vp, vp, sz, vp]
+    lib.droid_ba_profile_iteration.argtypes = [vp] * 9 + [c_int] * 7 + [c_float, c_float, c_int, vp, sz, vp, vp]
     lib.droid_ba_system.argtypes = [vp] + [c_int] * 7 + [ctypes.POINTER(sz)]
     lib.droid_ba_system.restype = vp
     lib.droid_ba_status.argtypes = [vp, vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]

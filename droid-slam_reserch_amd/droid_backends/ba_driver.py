@@ -1,0 +1,186 @@
+"""Phase-level driver of the dense BA: single GPU and edge-sharded multi-GPU (one process per
+GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
+
+Sharding: the factor graph is partitioned BY SOURCE FRAME.  Rank g owns a
+contiguous range of frames [f0,f1), the depth maps of those frames and every edge whose source
+`ii` lies in the range.  Per Gauss-Newton iteration each rank linearises its edges and reduces its
+depth frames locally (Hii/Hij/Hjj blocks, -E C^-1 E^T, rhs) into the dense (6P+1)^2 fp64 system,
+ONE all-reduce(sum) combines the systems, every rank then runs the identical Cholesky solve (dx
+is bit-identical on all ranks), back-substitutes its own depth frames and applies the same pose
+retraction.  No other collective is on the data path; `gather_disps` optionally re-assembles the
+depth maps at the end of a call.
+
+The compute backend is pluggable so that the host logic (partition, collective, phase order) is
+covered by world_size-2 gloo tests on CPU; the product backend is `HipBackend` (C ABI).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class BAProblemDev:
+    """Device tensors of one rank, shaped like the reference's `ba` arguments (droid.cpp:88-102)."""
+    poses: torch.Tensor       # [nbuf,7] f32, replicated on all ranks
+    disps: torch.Tensor       # [nbuf,H,W] f32, valid for owned frames
+    intrinsics: torch.Tensor  # [4]
+    disps_sens: torch.Tensor  # [nbuf,H,W]
+    targets: torch.Tensor     # [E_local,2,H,W]
+    weights: torch.Tensor     # [E_local,2,H,W]
+    eta: torch.Tensor         # [M_local,H,W]  rows = depth slots of THIS rank, ascending frame
+    ii: torch.Tensor          # [E_local] int64
+    jj: torch.Tensor          # [E_local] int64
+
+
+def partition_frames(ii, n_frames, world):
+    """Contiguous frame ranges [(f0,f1)] * world balanced by outgoing-edge count (host side)."""
+    ii = torch.as_tensor(ii).cpu().to(torch.int64)
+    deg = torch.bincount(ii, minlength=n_frames).to(torch.float64) + 1e-3  # every frame costs a little
+    csum = torch.cumsum(deg, 0)
+    total = float(csum[-1])
+    bounds = [0]
+    for r in range(1, world):
+        f = int(torch.searchsorted(csum, torch.tensor(total * r / world, dtype=torch.float64)).item()) + 1
+        bounds.append(min(max(f, bounds[-1]), n_frames))
+    bounds.append(n_frames)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def local_eta_rows(ii_local, t0, t1, own):
+    """Frames (ascending) that own a depth slot on this rank: unique(ii_local) U ([t0,t1) n own)."""
+    w0, w1 = max(t0, own[0]), min(t1, own[1])
+    fr = torch.unique(torch.cat([torch.as_tensor(ii_local).cpu().to(torch.int64),
+                                 torch.arange(w0, max(w0, w1), dtype=torch.int64)]))
+    return fr
+
+
+class HipBackend:
+    """The product compute backend: include/droid_backends_hip.h phase API on the current stream."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.ws = None
+
+    def _args(self, p: BAProblemDev, t0, t1, motion_only):
+        nbuf, H, W = p.disps.shape
+        E = int(p.ii.shape[0])
+        M = 0 if motion_only else int(p.eta.shape[0])
+        return E, int(nbuf), int(H), int(W), M, int(t0), int(t1)
+
+    def prepare(self, p: BAProblemDev, t0, t1, own, motion_only):
+        E, nbuf, H, W, M, t0, t1 = self._args(p, t0, t1, motion_only)
+        nbytes = self.lib.droid_ba_workspace_bytes(E, nbuf, H, W, t0, t1, M)
+        if nbytes == 0:
+            raise RuntimeError("ba: bad sizes / window")
+        if self.ws is None or self.ws.numel() < nbytes:
+            self.ws = torch.empty(nbytes + 4096, dtype=torch.uint8, device=p.poses.device)
+        self._dims = (E, nbuf, H, W, M, t0, t1)
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.lib.droid_ba_prepare(p.ii.data_ptr(), p.jj.data_ptr(), E, nbuf, H, W, M, t0, t1,
+                                             int(own[0]), int(own[1]), int(motion_only), self.ws.data_ptr(),
+                                             self.ws.numel(), s), "ba_prepare")
+        nel = ctypes.c_size_t(0)
+        ptr = self.lib.droid_ba_system(self.ws.data_ptr(), E, nbuf, H, W, t0, t1, M, ctypes.byref(nel))
+        off = ptr - self.ws.data_ptr()
+        self.system = self.ws[off:off + nel.value * 8].view(torch.float64)
+        self.dx = torch.empty((t1 - t0, 6), dtype=torch.float32, device=p.poses.device)
+        self.dz = torch.empty((M, H * W), dtype=torch.float32, device=p.poses.device)
+
+    def build(self, p: BAProblemDev, motion_only):
+        E, nbuf, H, W, M, t0, t1 = self._dims
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.lib.droid_ba_build(p.poses.data_ptr(), p.disps.data_ptr(), p.intrinsics.data_ptr(),
+                                           p.disps_sens.data_ptr(), p.targets.data_ptr(), p.weights.data_ptr(),
+                                           p.eta.data_ptr() if M > 0 else None, p.ii.data_ptr(), p.jj.data_ptr(),
+                                           E, nbuf, H, W, M, t0, t1, int(motion_only), self.ws.data_ptr(),
+                                           self.ws.numel(), s), "ba_build")
+        return self.system
+
+    def solve_update(self, p: BAProblemDev, lm, ep, motion_only):
+        E, nbuf, H, W, M, t0, t1 = self._dims
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.lib.droid_ba_solve_update(p.poses.data_ptr(), p.disps.data_ptr(), p.ii.data_ptr(),
+                                                  p.jj.data_ptr(), E, nbuf, H, W, M, t0, t1, float(lm), float(ep),
+                                                  int(motion_only), self.dx.data_ptr(),
+                                                  self.dz.data_ptr() if M > 0 else None, self.ws.data_ptr(),
+                                                  self.ws.numel(), s), "ba_solve_update")
+        return self.dx
+
+    def profile_iteration(self, p: BAProblemDev, lm, ep, motion_only):
+        """Stage times in ms of one iteration (measurement support, synchronises)."""
+        E, nbuf, H, W, M, t0, t1 = self._dims
+        ms = (ctypes.c_float * 8)()
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.lib.droid_ba_profile_iteration(
+            p.poses.data_ptr(), p.disps.data_ptr(), p.intrinsics.data_ptr(), p.disps_sens.data_ptr(),
+            p.targets.data_ptr(), p.weights.data_ptr(), p.eta.data_ptr() if M > 0 else None, p.ii.data_ptr(),
+            p.jj.data_ptr(), E, nbuf, H, W, M, t0, t1, float(lm), float(ep), int(motion_only),
+            self.ws.data_ptr(), self.ws.numel(), s, ms), "ba_profile_iteration")
+        names = ["linearize", "assemble", "schur", "rhs", "factor", "backsolve", "update", "total"]
+        return dict(zip(names, [float(x) for x in ms]))
+
+    def status(self):
+        st, m = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self.lib.droid_ba_status(self.ws.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                                            ctypes.byref(st), ctypes.byref(m)), "ba_status")
+        return st.value, m.value
+
+
+class ShardedBA:
+    """`iterations` Gauss-Newton steps over an edge-sharded graph.  world_size 1 degenerates to
+    the single-GPU path (no collective is issued)."""
+
+    def __init__(self, backend=None, group=None):
+        self.backend = backend if backend is not None else HipBackend()
+        self.group = group
+
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
+
+    def run(self, p: BAProblemDev, t0, t1, iterations, lm, ep, own=None, motion_only=False):
+        import torch.distributed as dist
+        world = self._world()
+        nbuf = int(p.disps.shape[0])
+        own = (0, nbuf) if own is None else own
+        be = self.backend
+        be.prepare(p, t0, t1, own, motion_only)
+        for _ in range(int(iterations)):
+            system = be.build(p, motion_only)
+            if world > 1:
+                dist.all_reduce(system, op=dist.ReduceOp.SUM, group=self.group)
+            be.solve_update(p, lm, ep, motion_only)
+        return be.dx
+
+    def gather_disps(self, disps, ranges):
+        """All ranks end up with every owner's depth maps (one all-reduce of the masked buffer)."""
+        import torch.distributed as dist
+        world = self._world()
+        if world == 1:
+            return disps
+        rank = dist.get_rank(self.group)
+        buf = torch.zeros_like(disps)
+        f0, f1 = ranges[rank]
+        buf[f0:f1] = disps[f0:f1]
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        disps.copy_(buf)
+        return disps
+
+
+def shard_problem(prob, ranges, rank):
+    """Host-side split of a synthetic BAProblem (numpy) into rank-local arrays."""
+    import numpy as np
+    f0, f1 = ranges[rank]
+    keep = (prob.ii >= f0) & (prob.ii < f1)
+    kx_all = np.unique(np.concatenate([np.arange(prob.t0, prob.t1), prob.ii]))
+    fr = local_eta_rows(prob.ii[keep], prob.t0, prob.t1, (f0, f1)).numpy()
+    rows = np.searchsorted(kx_all, fr)
+    return dict(targets=prob.targets[keep], weights=prob.weights[keep], ii=prob.ii[keep], jj=prob.jj[keep],
+                eta=prob.eta[rows], own=(f0, f1))

@@ -114,6 +114,16 @@ int droid_ba_solve_update(float *poses, float *disps, const int64_t *ii, const i
                           int motion_only, float *dx_out, float *dz_out, void *workspace,
                           size_t workspace_bytes, void *stream);
 
+/* Measurement support (bench.py): one Gauss-Newton iteration after droid_ba_prepare with a HIP
+ * event between kernel groups on `stream`; synchronises.  stage_ms[8] = {memset+linearise,
+ * assemble, Schur SYRK, rhs, damp+Cholesky factor, triangular back-solve, state update, total}. */
+int droid_ba_profile_iteration(float *poses, float *disps, const float *intrinsics,
+                               const float *disps_sens, const float *targets, const float *weights,
+                               const float *eta, const int64_t *ii, const int64_t *jj, int E,
+                               int nbuf, int H, int W, int M, int t0, int t1, float lm, float ep,
+                               int motion_only, void *workspace, size_t workspace_bytes,
+                               void *stream, float *stage_ms);
+
 /* Device address / element count of the dense fp64 system inside the workspace. */
 double *droid_ba_system(void *workspace, int E, int nbuf, int H, int W, int t0, int t1, int M,
                         size_t *n_elements);
