@@ -253,7 +253,7 @@ double* droid_ba_system(void* workspace, int E, int nbuf, int H, int W, int t0, 
   BaView v;
   if (!workspace || t1 <= t0) return nullptr;
   ba_carve(v, workspace, E, nbuf, H, W, t0, t1, M);
-  if (n_elements) *n_elements = (size_t)v.ld * v.ld;
+  if (n_elements) *n_elements = (size_t)(v.n + 1) * v.ld;
   return v.sys;
 }
 
@@ -275,7 +275,7 @@ int droid_chol_solve(const double* A, const double* b, double* x, int n, double*
                      int* fail_flag, void* stream) {
   if (n <= 0 || !A || !b || !x || !scratch || !fail_flag) return fail(DROID_E_ARG, "chol_solve: bad %s", "argument");
   hipStream_t s = (hipStream_t)stream;
-  const int ld = n + 1;
+  const int ld = (n + 1 + 7) & ~7;
   (void)hipMemsetAsync(fail_flag, 0, sizeof(int), s);
   launch_chol_pack(A, b, scratch, n, ld, s);
   launch_chol_solve(scratch, n, ld, 0.0, 0.0, x, fail_flag, s);

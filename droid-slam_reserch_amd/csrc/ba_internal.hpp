@@ -20,7 +20,7 @@ enum { STATUS_BAD_INDEX = 1, STATUS_ETA_ROWS = 2, STATUS_CHOL_FAIL = 4 };
 struct BaView {
   int E, nbuf, H, W, HW;
   int t0, t1, P, M;        // window, poses in it, depth slots the host sized the buffers for
-  int n, ld;               // n = 6P unknowns; system is ld x ld with ld = n + 1 (row n = rhs)
+  int n, ld;               // n = 6P unknowns; system is (n+1) x ld, ld = roundup8(n+1), row n = rhs
   int nch;                 // pixel chunks of the linearisation kernel
   int own0, own1;          // frames whose depth this rank owns
   int motion_only;         // prep: validate indices only, no depth slots
@@ -38,7 +38,7 @@ struct BaView {
   float* Q;                // [M][HW] 1/C
   float* w;                // [M][HW]
   float* Erows;            // [M+E][6][HW]: self rows Ei, then Eij rows
-  double* sys;             // [ld][ld] reduced camera system, lower triangle, row n = rhs
+  double* sys;             // [n+1][ld] reduced camera system, lower triangle, row n = rhs
   double* xsol;            // [ld] solve scratch / solution
   float* dx;               // [P][6]
 };
@@ -51,7 +51,7 @@ struct BaSizes {
 inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t0, int t1, int M) {
   v.E = E; v.nbuf = nbuf; v.H = H; v.W = W; v.HW = H * W;
   v.t0 = t0; v.t1 = t1; v.P = t1 - t0; v.M = M;
-  v.n = 6 * v.P; v.ld = v.n + 1;
+  v.n = 6 * v.P; v.ld = (v.n + 1 + 7) & ~7;
   v.nch = (v.HW + LIN_CP - 1) / LIN_CP;
   v.own0 = 0; v.own1 = nbuf; v.motion_only = 0;
   size_t off = 0;
@@ -75,7 +75,7 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.Q = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
   v.w = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
   v.Erows = static_cast<float*>(take(sizeof(float) * (M > 0 ? ((size_t)M + E) * 6 * v.HW + 4 : 4)));
-  v.sys = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld * v.ld + 1)));
+  v.sys = static_cast<double*>(take(sizeof(double) * ((size_t)(v.n + 1) * v.ld + 8)));
   v.xsol = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld + 1)));
   v.dx = static_cast<float*>(take(sizeof(float) * ((size_t)v.n + 8)));
   return off;

@@ -638,7 +638,7 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
   const bool depth = !motion_only && v.M > 0;
   switch (stage) {
     case 0:
-      (void)hipMemsetAsync(v.sys, 0, sizeof(double) * (size_t)v.ld * v.ld, s);
+      (void)hipMemsetAsync(v.sys, 0, sizeof(double) * (size_t)(v.n + 1) * v.ld, s);
       if (depth)
         hipLaunchKernelGGL(ba_lin_kernel<true>, dim3(v.M, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
                            disps, intr, sens, targets, weights, eta, ii, jj);

@@ -4,15 +4,20 @@
 // /root/reference/src/droid_kernels.cu:1192-1213): same damping `diag += ep + lm*diag` (:1197),
 // same fp64 LL^T factorisation of the same matrix, failure => caller zeroes dx (:1207-1210).
 //
-// Layout: S is ld x ld row-major with ld = n + 1; the lower triangle of S[0:n,0:n] is the
-// matrix, row n holds the right-hand side.  Factoring the augmented matrix turns row n into
+// Layout: S is (n+1) x ld row-major, ld = n+1 rounded up to a multiple of 8 (64-byte rows); the
+// lower triangle of S[0:n,0:n] is the matrix, row n holds the right-hand side.  Factoring the augmented matrix turns row n into
 // y^T = (L^-1 b)^T for free (the forward substitution rides along with the panel TRSM), so only
 // the backward substitution L^T x = y remains.
 //
-// Blocked right-looking factorisation, NB = 64, two launches per block column:
-//   panel : every row block re-factors the 64x64 diagonal block in LDS (cheaper than a grid
-//           hand-off) and solves its own rows against it,
-//   update: A22 -= L21 L21^T on 64x64 tiles (lower tiles only).
+// The solve is a latency chain (n = 6P sequential pivots), not a flop problem, so the design
+// minimises the dependent path per pivot:
+//   * blocked right-looking factorisation, NB = 64, two launches per block column;
+//   * panel kernel: every row block re-factors the 64x64 diagonal block in LDS (cheaper than a
+//     grid-wide hand-off) as 4 steps of {16x16 in-register wave factorisation with
+//     readlane-broadcast pivots and an rsqrt+Newton pivot reciprocal (no fp64 sqrt/div on the
+//     chain), row-parallel 16-wide triangular solve, v_mfma_f64_16x16x4 block updates}, then
+//     solves its own 64 rows against it the same way;
+//   * update kernel: A22 -= L21 L21^T, one 64x64 tile per workgroup on v_mfma_f64_16x16x4.
 #include <hip/hip_runtime.h>
 
 #include "ba_internal.hpp"
@@ -20,6 +25,64 @@
 namespace droid {
 
 constexpr int NB = CHOL_NB;
+constexpr int LDP = NB + 2;  // LDS row pitch in doubles: rows stay 16-B aligned, b64 MFMA operand reads conflict-free
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// Cooperative load of a 64x64 fp64 tile (rows r0.., cols c0..c0+63 of S) into LDS by 256 threads:
+// 8 independent 16-byte loads per thread are issued before the first LDS store, so the tile costs
+// one memory round trip instead of sixteen.  Rows >= row_end and columns >= col_end read as
+// `fill_diag` on the (tile-local) diagonal and 0 elsewhere; with `lower` only j <= i is kept.
+// Requires ld % 2 == 0 and c0 % 2 == 0 (16-byte aligned rows).
+__device__ __forceinline__ void load_tile64(double* __restrict__ dst, const double* __restrict__ S,
+                                            int ld, int r0, int c0, int row_begin, int row_end,
+                                            int col_end, bool lower, double fill_diag) {
+  const int t = threadIdx.x;
+  f64x2 v[8];
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int idx2 = it * 256 + t;
+    const int i = idx2 >> 5, j = (idx2 & 31) * 2;
+    const bool ok = (r0 + i >= row_begin) && (r0 + i < row_end) && (c0 + j < col_end);
+    const double* p = S + (size_t)(ok ? r0 + i : 0) * ld + (ok ? c0 + j : 0);
+    v[it] = *reinterpret_cast<const f64x2*>(p);
+    if (!ok) v[it] = (f64x2){0.0, 0.0};
+  }
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int idx2 = it * 256 + t;
+    const int i = idx2 >> 5, j = (idx2 & 31) * 2;
+    double a = v[it][0], b = v[it][1];
+    const bool rok = (r0 + i >= row_begin) && (r0 + i < row_end);
+    if (!(rok && c0 + j + 1 < col_end)) b = 0.0;
+    if (lower) {
+      if (j > i) a = 0.0;
+      if (j + 1 > i) b = 0.0;
+    }
+    if (fill_diag != 0.0) {
+      if (j == i && !(rok && c0 + j < col_end)) a = fill_diag;
+      if (j + 1 == i && !(rok && c0 + j + 1 < col_end)) b = fill_diag;
+    }
+    *reinterpret_cast<f64x2*>(&dst[i * LDP + j]) = (f64x2){a, b};
+  }
+}
+
+// Store rows [row_begin,row_end) x cols [0,ncols) of an LDS tile back (optionally lower part only).
+__device__ __forceinline__ void store_tile64(double* __restrict__ S, const double* __restrict__ src,
+                                             int ld, int r0, int c0, int row_begin, int row_end,
+                                             int ncols, bool lower) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const int idx = it * 256 + t;
+    const int i = idx >> 6, j = idx & 63;
+    if (r0 + i >= row_begin && r0 + i < row_end && j < ncols && (!lower || j <= i))
+      S[(size_t)(r0 + i) * ld + c0 + j] = src[i * LDP + j];
+  }
+}
 
 __global__ void chol_damp_kernel(double* __restrict__ S, int n, int ld, double lm, double ep) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -29,146 +92,239 @@ __global__ void chol_damp_kernel(double* __restrict__ S, int n, int ld, double l
   }
 }
 
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ S, int n, int ld, int k,
-                                                         int* __restrict__ fail) {
-  __shared__ double L[NB][NB + 1];
-  __shared__ double X[NB][NB + 1];
-  __shared__ double dg[NB];
-  const int t = threadIdx.x;
-  const int c0 = k * NB;
-  const int wk = min(NB, n - c0);
-  const int rb = k + blockIdx.x;
-  const int r0 = rb * NB;
-  const int r1 = min(r0 + NB, ld);
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int i = idx / NB, j = idx % NB;
-    double val = 0.0;
-    if (i < wk && j <= i) val = S[(size_t)(c0 + i) * ld + c0 + j];
-    L[i][j] = val;
-  }
-  // rows of this block that lie below the diagonal block
-  const int s0 = max(r0, c0 + wk);
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int i = idx / NB, j = idx % NB;
-    double val = 0.0;
-    if (r0 + i >= s0 && r0 + i < r1 && j < wk) val = S[(size_t)(r0 + i) * ld + c0 + j];
-    X[i][j] = val;
-  }
-  __syncthreads();
+// 1/sqrt(d) to fp64 accuracy: fp32 seed + two Newton steps (quadratic: 6e-8 -> 5e-15 -> 1e-16).
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = (double)__frsqrt_rn((float)d);
+  double e = fma(-d * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-d * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  return y;
+}
 
-  // unblocked Cholesky of the diagonal block in LDS
-  for (int j = 0; j < wk; j++) {
-    double d = L[j][j];
-    if (!(d > 0.0)) {
-      if (t == 0 && blockIdx.x == 0) *fail = 1;
-      d = 1.0;
-    }
-    d = sqrt(d);
-    if (t == 0) dg[j] = d;
-    if (t > j && t < wk) L[t][j] = L[t][j] / d;
-    __syncthreads();
-    const int i = t & 63;
-    if (i > j && i < wk) {
-      const double lij = L[i][j];
-      for (int c = j + 1 + (t >> 6); c <= i; c += 4) L[i][c] -= lij * L[c][j];
-    }
-    __syncthreads();
-  }
-
-  // write the factor of the diagonal block (the row block that contains it)
-  if (rb == k) {
-    for (int idx = t; idx < NB * NB; idx += 256) {
-      const int i = idx / NB, j = idx % NB;
-      if (i < wk && j <= i) S[(size_t)(c0 + i) * ld + c0 + j] = (i == j) ? dg[i] : L[i][j];
-    }
-  }
-
-  // X L^T = A  for the rows below: 4 lanes per row, each owning the columns c = part (mod 4)
-  {
-    const int i = t >> 2, part = t & 3;
-    const bool active = (r0 + i >= s0) && (r0 + i < r1);
-    for (int j = 0; j < wk; j++) {
-      double s = 0.0;
-      if (active)
-        for (int c = part; c < j; c += 4) s += X[i][c] * L[j][c];
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      if (active && part == (j & 3)) X[i][j] = (X[i][j] - s) / dg[j];
-    }
-  }
-  __syncthreads();
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int i = idx / NB, j = idx % NB;
-    if (r0 + i >= s0 && r0 + i < r1 && j < wk) S[(size_t)(r0 + i) * ld + c0 + j] = X[i][j];
+// C(16x16) -= A(16x16) * B(16x16)^T on one wave.  A, C: LDS blocks with row pitch LDP; B: LDS
+// block with row pitch ldb.  v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4], B^T[l>>4][l&15];
+// result register i of lane l is D[(l>>4) + 4i][l&15].
+template <bool ASSIGN>
+__device__ __forceinline__ void wave_gemm_nt16(double* C, const double* A, const double* B, int ldb) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 16; k += 4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[r * LDP + k + g], B[r * ldb + k + g], acc, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double* c = &C[(g + 4 * i) * LDP + r];
+    *c = ASSIGN ? acc[i] : *c - acc[i];
   }
 }
 
-__global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ S, int n, int ld,
-                                                          int k) {
-  __shared__ double Lr[NB][NB + 1];
-  __shared__ double Lc[NB][NB + 1];
-  const int bi = k + 1 + blockIdx.x, bj = k + 1 + blockIdx.y;
+// In-register Cholesky of the 16x16 block at Lb (LDS, pitch LDP) by one wave.  Lane l < 16 holds
+// row l of the block; lanes 16..31 hold the rows of the identity.  The factorisation is a chain
+// of column operations (scale column j, subtract multiples of it from the later columns) whose
+// scalars travel by v_readlane; applied to the identity rows as well they leave L^-T there, so
+// the inverse comes for free and every triangular solve against this block becomes a GEMM.
+// Outputs: L (lower part, in place) and Wl[j*16 + k] = (L^-1)[j][k].
+__device__ __forceinline__ void wave_potrf16(double* Lb, double* Wl, int* fail, bool report) {
+  const int lane = threadIdx.x & 63, row = lane & 15;
+  const bool ident = (lane & 16) != 0;
+  double a[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const double v = Lb[row * LDP + c];
+    a[c] = ident ? ((c == row) ? 1.0 : 0.0) : v;
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    double d = readlane_f64(a[j], j);
+    if (!(d > 0.0)) {
+      bad = true;
+      d = 1.0;
+    }
+    const double y = rsqrt_nr(d);
+    a[j] = (lane == j) ? d * y : a[j] * y;
+#pragma unroll
+    for (int c = j + 1; c < 16; c++) {
+      const double s = readlane_f64(a[j], c);
+      a[c] = fma(-a[j], s, a[c]);
+    }
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; c++)
+      if (c <= row) Lb[row * LDP + c] = a[c];
+  } else if (lane < 32) {  // lane 16+k holds row k of L^-T: (L^-1)[j][k] = a[j]
+#pragma unroll
+    for (int j = 0; j < 16; j++) Wl[j * 16 + row] = a[j];
+  }
+  if (lane == 0 && bad && report) *fail = 1;
+}
+
+// 64x64 tile update on one workgroup: acc (wave w: rows 16w..16w+15, all 64 columns) -= Lr Lc^T.
+__device__ __forceinline__ void tile_update64(f64x4 (&acc)[4], const double* Lr, const double* Lc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const double* Ar = &Lr[(16 * wave + r) * LDP + g];
+#pragma unroll 4
+  for (int kk = 0; kk < NB; kk += 4) {
+    const double a = -Ar[kk];
+#pragma unroll
+    for (int nn = 0; nn < 4; nn++)
+      acc[nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lc[(16 * nn + r) * LDP + kk + g], acc[nn], 0, 0, 0);
+  }
+}
+
+// accumulator fragment <-> global / LDS tile (row = 16*wave + (lane>>4) + 4i, col = 16nn + (lane&15))
+__device__ __forceinline__ void frag_load_global(f64x4 (&acc)[4], const double* __restrict__ S, int ld,
+                                                 int r0, int q0, int row_end, int col_end, bool lower) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int nn = 0; nn < 4; nn++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int li = 16 * wave + g + 4 * i, lj = 16 * nn + r;
+      const int row = r0 + li, col = q0 + lj;
+      double v = 0.0;
+      if (row < row_end && col < col_end && (!lower || lj <= li)) v = S[(size_t)row * ld + col];
+      acc[nn][i] = v;
+    }
+}
+
+__device__ __forceinline__ void frag_store_lds(const f64x4 (&acc)[4], double* T) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int nn = 0; nn < 4; nn++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) T[(16 * wave + g + 4 * i) * LDP + 16 * nn + r] = acc[nn][i];
+}
+
+// One step of the blocked right-looking factorisation in ONE launch:
+//   every tile (bi >= bj > k) of the trailing matrix:  A[bi,bj] -= L[bi,k] L[bj,k]^T
+//   tiles of block column k+1 additionally finish panel k+1: they rebuild and factor the updated
+//   diagonal tile A[k+1,k+1] (redundantly per workgroup: cheaper than a grid hand-off) and solve
+//   their own tile against it, so panel k+1 is ready when the launch ends.
+// k = -1 is the initial panel (no update).  Grid: (row blocks, column blocks) from k+1.
+__global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ S, int n, int ld, int k,
+                                                        int* __restrict__ fail) {
+  __shared__ double B0[NB * LDP];   // L[bi,k], later the own tile T / X
+  __shared__ double B1[NB * LDP];   // L[bj,k], later the diagonal tile D / L
+  __shared__ double Wl[4 * 256];    // inverses of the four 16x16 diagonal blocks
+  const int nrows = n + 1;          // row n = right-hand side
+  const int kp = k + 1;             // block column being finished
+  const int bi = kp + blockIdx.x, bj = kp + blockIdx.y;
   if (bj > bi) return;
-  const int t = threadIdx.x;
-  const int p0 = k * NB;  // the panel is a full block whenever a trailing column block exists
+  const int t = threadIdx.x, wave = t >> 6;
   const int r0 = bi * NB, q0 = bj * NB;
+  const int c0 = kp * NB;                 // panel column
+  const int wk = min(NB, n - c0);         // its width
+  const bool panel = (bj == kp);
+  const bool diag = panel && (bi == kp);
+
+  f64x4 accT[4], accD[4];
+  // own tile (lower part only on the diagonal of the matrix) and, for panel workgroups, the
+  // diagonal tile of the panel column; both straight into MFMA accumulator layout
+  frag_load_global(accT, S, ld, r0, q0, nrows, n, bi == bj);
+  if (panel && !diag) frag_load_global(accD, S, ld, c0, c0, c0 + wk, c0 + wk, true);
+  if (k >= 0) {
+    const int p0 = k * NB;
+    load_tile64(B0, S, ld, r0, p0, r0, nrows, p0 + NB, false, 0.0);
+    if (!diag && bi != bj) load_tile64(B1, S, ld, q0, p0, q0, n, p0 + NB, false, 0.0);
+    __syncthreads();
+    const double* Lc = (bi == bj) ? B0 : B1;
+    tile_update64(accT, B0, Lc);
+    if (panel && !diag) tile_update64(accD, B1, B1);
+    __syncthreads();
+  }
+  if (!panel) {  // plain trailing tile: write back
+    const int lane = t & 63, r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int nn = 0; nn < 4; nn++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int li = 16 * wave + g + 4 * i, lj = 16 * nn + r;
+        const int row = r0 + li, col = q0 + lj;
+        if (row < nrows && col < n && (bi != bj || lj <= li)) S[(size_t)row * ld + col] = accT[nn][i];
+      }
+    return;
+  }
+
+  // panel workgroup: B1 <- diagonal tile (identity-padded), B0 <- the rows to solve: the own tile,
+  // or for the diagonal workgroup the rows of its block below the diagonal tile (only the rhs row,
+  // and only when the last block column is narrower than NB)
+  const bool solve_rows = !diag || (wk < NB);
+  frag_store_lds(diag ? accT : accD, B1);
+  if (solve_rows) frag_store_lds(accT, B0);
+  __syncthreads();
   for (int idx = t; idx < NB * NB; idx += 256) {
-    const int i = idx / NB, j = idx % NB;
-    Lr[i][j] = (r0 + i < ld) ? S[(size_t)(r0 + i) * ld + p0 + j] : 0.0;
-    Lc[i][j] = (q0 + i < n) ? S[(size_t)(q0 + i) * ld + p0 + j] : 0.0;
+    const int i = idx >> 6, j = idx & 63;
+    if (j > i) B1[i * LDP + j] = 0.0;  // strict upper part
+    else if (i >= wk || j >= wk) B1[i * LDP + j] = (i == j) ? 1.0 : 0.0;  // identity padding
+    if (diag && solve_rows && !(i >= wk && r0 + i < nrows && j < wk)) B0[i * LDP + j] = 0.0;
   }
   __syncthreads();
-  const int ti = t >> 4, tj = t & 15;
-  double acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
-  for (int j = 0; j < NB; j++) {
-    double a[4], b[4];
-#pragma unroll
-    for (int x = 0; x < 4; x++) {
-      a[x] = Lr[4 * ti + x][j];
-      b[x] = Lc[4 * tj + x][j];
+
+  for (int p = 0; p < 4; p++) {
+    if (wave == 0) wave_potrf16(&B1[(16 * p) * LDP + 16 * p], &Wl[256 * p], fail, diag);
+    __syncthreads();
+    {  // triangular solves as GEMMs with the block inverse: L_qp = D_qp W^T, X_gp = T_gp W^T
+      int cnt = 0;
+      for (int q = p + 1; q < 4; q++, cnt++)
+        if ((cnt & 3) == wave)
+          wave_gemm_nt16<true>(&B1[(16 * q) * LDP + 16 * p], &B1[(16 * q) * LDP + 16 * p], &Wl[256 * p], 16);
+      if (solve_rows)
+        for (int g = 0; g < 4; g++, cnt++)
+          if ((cnt & 3) == wave)
+            wave_gemm_nt16<true>(&B0[(16 * g) * LDP + 16 * p], &B0[(16 * g) * LDP + 16 * p], &Wl[256 * p], 16);
     }
-#pragma unroll
-    for (int x = 0; x < 4; x++)
-#pragma unroll
-      for (int y = 0; y < 4; y++) acc[x][y] += a[x] * b[y];
-  }
-#pragma unroll
-  for (int x = 0; x < 4; x++) {
-    const int r = r0 + 4 * ti + x;
-    if (r >= ld) continue;
-#pragma unroll
-    for (int y = 0; y < 4; y++) {
-      const int c = q0 + 4 * tj + y;
-      if (c < n && c <= r) S[(size_t)r * ld + c] -= acc[x][y];
+    __syncthreads();
+    {  // trailing 16x16 blocks: D_rs -= L_rp L_sp^T (r >= s > p), T_gq -= X_gp L_qp^T (q > p)
+      int cnt = 0;
+      for (int r = p + 1; r < 4; r++)
+        for (int s2 = p + 1; s2 <= r; s2++, cnt++)
+          if ((cnt & 3) == wave)
+            wave_gemm_nt16<false>(&B1[(16 * r) * LDP + 16 * s2], &B1[(16 * r) * LDP + 16 * p],
+                                  &B1[(16 * s2) * LDP + 16 * p], LDP);
+      if (solve_rows)
+        for (int g = 0; g < 4; g++)
+          for (int q = p + 1; q < 4; q++, cnt++)
+            if ((cnt & 3) == wave)
+              wave_gemm_nt16<false>(&B0[(16 * g) * LDP + 16 * q], &B0[(16 * g) * LDP + 16 * p],
+                                    &B1[(16 * q) * LDP + 16 * p], LDP);
     }
+    __syncthreads();
   }
+  if (diag) store_tile64(S, B1, ld, c0, c0, c0, c0 + wk, wk, true);
+  if (solve_rows) store_tile64(S, B0, ld, r0, c0, max(r0, c0 + wk), min(r0 + NB, nrows), wk, false);
 }
 
 // One block column of the backward substitution L^T x = y (y = row n of S, consumed in place):
 // x_k = L_kk^-T y_k, then y[0:c0] -= L[k rows, 0:c0]^T x_k.
 __global__ __launch_bounds__(256) void chol_backsolve_kernel(double* __restrict__ S, int n, int ld,
                                                              int k, double* __restrict__ x) {
-  __shared__ double L[NB][NB + 1];
+  __shared__ double L[NB * LDP];
   __shared__ double xk[NB];
   const int t = threadIdx.x;
   const int c0 = k * NB;
   const int wk = min(NB, n - c0);
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int i = idx / NB, j = idx % NB;
-    L[i][j] = (i < wk && j <= i) ? S[(size_t)(c0 + i) * ld + c0 + j] : 0.0;
-  }
+  load_tile64(L, S, ld, c0, c0, c0, c0 + wk, c0 + wk, true, 1.0);
   __syncthreads();
   if (t < 64) {
+    // lane j owns z_j; column-oriented back substitution with static lane broadcasts
     double z = (t < wk) ? S[(size_t)n * ld + c0 + t] : 0.0;
-    for (int i = wk - 1; i >= 0; i--) {
-      const double xi = __shfl(z, i) / L[i][i];
-      if (t == i) z = xi;
-      if (t < i) z -= L[i][t] * xi;
+    const double rinv = 1.0 / L[t * LDP + t];
+#pragma unroll
+    for (int i = NB - 1; i >= 0; i--) {
+      const double xi = readlane_f64(z * rinv, i);
+      z = (t == i) ? xi : ((t < i) ? fma(-L[i * LDP + t], xi, z) : z);
     }
     xk[t] = z;
   }
@@ -179,9 +335,17 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(double* __restrict_
   }
   const int c = (blockIdx.x - 1) * 256 + t;
   if (c < c0) {
-    double s = 0.0;
-    for (int r = 0; r < wk; r++) s += S[(size_t)(c0 + r) * ld + c] * xk[r];
-    S[(size_t)n * ld + c] -= s;
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    const double* col = S + (size_t)c0 * ld + c;
+#pragma unroll
+    for (int r = 0; r < NB; r += 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = (r + u < wk) ? col[(size_t)(r + u) * ld] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; u++) s4[u & 3] = fma(v[u], xk[r + u], s4[u & 3]);
+    }
+    S[(size_t)n * ld + c] -= (s4[0] + s4[1]) + (s4[2] + s4[3]);
   }
 }
 
@@ -189,14 +353,11 @@ void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* f
                         hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(chol_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sys, n, ld, lm, ep);
-  const int nb = (n + NB - 1) / NB;
-  const int nrb = (ld + NB - 1) / NB;
-  for (int k = 0; k < nb; k++) {
-    hipLaunchKernelGGL(chol_panel_kernel, dim3(nrb - k), dim3(256), 0, s, sys, n, ld, k, fail_flag);
-    if (k + 1 < nb)
-      hipLaunchKernelGGL(chol_update_kernel, dim3(nrb - k - 1, nb - k - 1), dim3(256), 0, s, sys, n,
-                         ld, k);
-  }
+  const int nb = (n + NB - 1) / NB;        // block columns
+  const int nrb = (n + 1 + NB - 1) / NB;   // block rows (row n = rhs)
+  for (int k = -1; k + 1 < nb; k++)         // launch k finishes panel k+1
+    hipLaunchKernelGGL(chol_step_kernel, dim3(nrb - k - 1, nb - k - 1), dim3(256), 0, s, sys, n, ld, k,
+                       fail_flag);
 }
 
 void launch_chol_backsolve(double* sys, int n, int ld, double* x, hipStream_t s) {
@@ -219,7 +380,7 @@ void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double*
 __global__ void chol_pack_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                  double* __restrict__ S, int n, int ld) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)ld * ld) return;
+  if (idx >= (size_t)(n + 1) * ld) return;
   const int r = (int)(idx / ld), c = (int)(idx % ld);
   double val = 0.0;
   if (r < n && c < n) val = A[(size_t)r * n + c];
@@ -228,7 +389,7 @@ __global__ void chol_pack_kernel(const double* __restrict__ A, const double* __r
 }
 
 void launch_chol_pack(const double* A, const double* b, double* S, int n, int ld, hipStream_t s) {
-  const size_t tot = (size_t)ld * ld;
+  const size_t tot = (size_t)(n + 1) * ld;
   hipLaunchKernelGGL(chol_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, b,
                      S, n, ld);
 }

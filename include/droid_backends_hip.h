@@ -92,9 +92,9 @@ int droid_ba(float *poses, float *disps, const float *intrinsics, const float *d
  *
  * droid_ba_prepare: once per call -- depth-slot table, CSR of edges by source frame.
  * droid_ba_build:   one linearisation: writes this rank's contribution to the reduced camera
- *                   system into the workspace: S = [ A - E C^-1 E^T | . ; b^T | . ] as a dense
- *                   (6P+1) x (6P+1) fp64 row-major matrix, lower triangle valid, row 6P = rhs,
- *                   no damping yet.  droid_ba_system() returns its device address so that the
+ *                   system into the workspace: S = [ A - E C^-1 E^T ; b^T ] as a dense fp64
+ *                   row-major matrix of 6P+1 rows with row pitch ld = roundup8(6P+1), lower
+ *                   triangle valid, row 6P = rhs, no damping yet.  droid_ba_system() returns its device address so that the
  *                   caller can all-reduce (sum) it over ranks (RCCL) before the solve.
  * droid_ba_solve_update: damping (diag += ep + lm*diag), Cholesky, solve, depth
  *                   back-substitution for the owned slots, SE3 / disparity retraction.
@@ -134,7 +134,7 @@ int droid_ba_status(const void *workspace, void *stream, int *status_out, int *d
 
 /* Dense SPD solve used by the BA (exposed for tests): A [n,n] fp64 row-major (lower triangle
  * read, destroyed), b [n] fp64 -> x [n] fp64.  fail_flag (device int) is set to 1 when a pivot
- * is not positive.  scratch: >= (n+1)*(n+1) doubles. */
+ * is not positive.  scratch: >= (n+1)*(n+8) doubles. */
 int droid_chol_solve(const double *A, const double *b, double *x, int n, double *scratch,
                      int *fail_flag, void *stream);
 
