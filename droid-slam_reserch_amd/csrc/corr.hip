@@ -77,13 +77,63 @@ __device__ __forceinline__ Bilin bilin_setup(float x0, float y0, int r) {
 }
 
 // ---- corr_index_forward ------------------------------------------------------------------
-// One thread per query pixel, 64 consecutive pixels per wave: the (2r+1)^2 outputs of a plane
-// offset are stores of 64 consecutive elements; the window rows are 2r+2 contiguous taps each.
+// One thread per query pixel, 64 consecutive pixels per wave: each of the (2r+1)^2 output planes
+// is written as 64 consecutive elements.  A query's window is (2r+2) rows of (2r+2) contiguous
+// taps in ITS OWN plane (planes of neighbouring queries are H2*W2 elements apart), so every row
+// lives in one or two cache lines that no other lane shares: each row is therefore fetched with
+// ONE dword-aligned wide load (16/32/64 B for f16/f32/f64 at r=3) instead of 2r+2 element loads,
+// which made every line travel through L1/L2 2r+2 times.  Taps outside the plane are masked to 0
+// after the load (reading the neighbouring row of the same tensor is harmless); only lanes whose
+// wide load would leave the tensor fall back to per-element loads.
+typedef uint32_t u32a4 __attribute__((aligned(4)));
+
+template <typename T, int NT>
+struct RowLoad;  // NT taps of type T starting at p (element aligned), fp32/fp64 work values
+
+template <int NT>
+struct RowLoad<__half, NT> {
+  static constexpr int NW = (NT * 2 + 2 + 3) / 4;  // dwords covering NT halfs at either parity
+  static __device__ __forceinline__ void load(const __half* p, float* tap) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const u32a4* q = reinterpret_cast<const u32a4*>(reinterpret_cast<const char*>(p) - (a & 2));
+    uint32_t w[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) w[k] = q[k];
+    const bool odd = (a & 2) != 0;
+#pragma unroll
+    for (int k = 0; k < NT / 2; k++) {
+      const uint32_t v = odd ? __builtin_amdgcn_alignbit(w[k + 1], w[k], 16) : w[k];
+      tap[2 * k] = __half2float(__ushort_as_half((unsigned short)(v & 0xffffu)));
+      tap[2 * k + 1] = __half2float(__ushort_as_half((unsigned short)(v >> 16)));
+    }
+  }
+  static __device__ __forceinline__ size_t span_bytes() { return NW * 4; }
+};
+
+template <int NT>
+struct RowLoad<float, NT> {
+  static __device__ __forceinline__ void load(const float* p, float* tap) {
+    const u32a4* q = reinterpret_cast<const u32a4*>(p);
+#pragma unroll
+    for (int k = 0; k < NT; k++) tap[k] = __uint_as_float(q[k]);
+  }
+  static __device__ __forceinline__ size_t span_bytes() { return NT * 4; }
+};
+
+template <int NT>
+struct RowLoad<double, NT> {
+  static __device__ __forceinline__ void load(const double* p, double* tap) {
+#pragma unroll
+    for (int k = 0; k < NT; k++) tap[k] = p[k];
+  }
+  static __device__ __forceinline__ size_t span_bytes() { return NT * 8; }
+};
+
 template <typename T, int R>
 __global__ __launch_bounds__(256) void corr_index_forward_kernel(const T* __restrict__ volume,
                                                                  const float* __restrict__ coords,
                                                                  T* __restrict__ corr, int H1W1,
-                                                                 int H2, int W2) {
+                                                                 int H2, int W2, size_t vol_elems) {
   typedef typename Elem<T>::work work;
   constexpr int RD = 2 * R + 1, NT = RD + 1;
   const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -93,18 +143,38 @@ __global__ __launch_bounds__(256) void corr_index_forward_kernel(const T* __rest
   const float y0 = coords[((size_t)b * 2 + 1) * H1W1 + pix];
   const Bilin bl = bilin_setup(x0, y0, R);
   const T* plane = volume + ((size_t)b * H1W1 + pix) * ((size_t)H2 * W2);
+  const uintptr_t vbeg = reinterpret_cast<uintptr_t>(volume);
+  const uintptr_t vend = vbeg + vol_elems * sizeof(T);
+  // any tap of the window inside the plane at all?
+  const bool xany = (bl.x1 + NT > 0) && (bl.x1 < W2);
 
   work tap[NT][NT];  // [row j (y)][col i (x)]
 #pragma unroll
   for (int j = 0; j < NT; j++) {
     const int y1 = bl.y1 + j;
-    const bool rowok = (y1 >= 0) && (y1 < H2);
-    const T* row = plane + (size_t)(rowok ? y1 : 0) * W2;
+    const bool rowok = xany && (y1 >= 0) && (y1 < H2);
 #pragma unroll
-    for (int i = 0; i < NT; i++) {
-      const int x1 = bl.x1 + i;
-      const bool ok = rowok && (x1 >= 0) && (x1 < W2);
-      tap[j][i] = ok ? Elem<T>::load(row + x1) : (work)0;
+    for (int i = 0; i < NT; i++) tap[j][i] = (work)0;
+    if (rowok) {
+      const T* rp = plane + (ptrdiff_t)y1 * W2 + bl.x1;
+      const uintptr_t a0 = reinterpret_cast<uintptr_t>(rp) & ~uintptr_t(3);
+      if (a0 >= vbeg && a0 + RowLoad<T, NT>::span_bytes() <= vend) {
+        RowLoad<T, NT>::load(rp, tap[j]);
+      } else {  // first / last elements of the whole tensor only
+#pragma unroll 1
+        for (int i = 0; i < NT; i++) {
+          const int x1 = bl.x1 + i;
+          const work v = (x1 >= 0 && x1 < W2) ? Elem<T>::load(rp + i) : (work)0;
+#pragma unroll
+          for (int i2 = 0; i2 < NT; i2++)
+            if (i2 == i) tap[j][i2] = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NT; i++) {
+        const int x1 = bl.x1 + i;
+        if (x1 < 0 || x1 >= W2) tap[j][i] = (work)0;
+      }
     }
   }
   const float one = 1.0f;
@@ -168,10 +238,11 @@ static int corr_index_forward_t(const void* volume, const float* coords, void* c
   dim3 grid((HW + 255) / 256, B), block(256);
   const T* v = static_cast<const T*>(volume);
   T* c = static_cast<T*>(corr);
+  const size_t vol_elems = (size_t)B * HW * H2 * W2;
   if (r == 3)
-    hipLaunchKernelGGL((corr_index_forward_kernel<T, 3>), grid, block, 0, s, v, coords, c, HW, H2, W2);
+    hipLaunchKernelGGL((corr_index_forward_kernel<T, 3>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems);
   else if (r == 4)
-    hipLaunchKernelGGL((corr_index_forward_kernel<T, 4>), grid, block, 0, s, v, coords, c, HW, H2, W2);
+    hipLaunchKernelGGL((corr_index_forward_kernel<T, 4>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems);
   else
     hipLaunchKernelGGL((corr_index_forward_generic<T>), grid, block, 0, s, v, coords, c, HW, H2, W2, r);
   return 0;
@@ -302,6 +373,207 @@ __global__ __launch_bounds__(256) void altcorr_forward_generic(const T* __restri
   }
 }
 
+// ---- altcorr_forward, fp32 fast path: LDS-staged fmap2 windows ------------------------------
+// One workgroup = an 8x8 tile of query pixels of one (edge, coordinate set).  The windows of
+// neighbouring queries overlap almost completely when the flow is locally coherent, so the
+// workgroup stages the bounding box of all 64 windows (<= ALT_MAXPOS positions) of fmap2 in LDS,
+// 32 channels at a time, and every (query, tap) dot product reads its fmap2 row from LDS with
+// 16-byte reads (row pitch 36 floats: conflict-free for neighbouring positions) against the
+// query's fmap1 chunk held in registers.  Wave w owns tap rows j = w (mod 4) of all 64 queries;
+// the (2r+2)^2 tap sums are exchanged through LDS for the bilinear combine.  Tiles whose bounding
+// box does not fit (incoherent coordinates) take the per-query path of the generic kernel.
+constexpr int ALT_TQ = 8;          // tile is ALT_TQ x ALT_TQ queries
+constexpr int ALT_MAXPOS = 448;    // fmap2 positions staged per tile
+#ifndef DROID_ALT_CH
+#define DROID_ALT_CH 32
+#endif
+constexpr int ALT_CH = DROID_ALT_CH;          // channels per stage
+constexpr int ALT_WAVES = 4;                  // waves per workgroup: wave w owns tap rows j = w (mod 4)
+constexpr int ALT_THREADS = 64 * ALT_WAVES;
+constexpr int ALT_PITCH = ALT_CH + 4;         // floats per staged position (pad keeps 16-B alignment)
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int R>
+__global__ __launch_bounds__(ALT_THREADS, 2) void altcorr_forward_tiled(const float* __restrict__ fmap1,
+                                                             const float* __restrict__ fmap2,
+                                                             const float* __restrict__ coords,
+                                                             float* __restrict__ corr, int N, int H1,
+                                                             int W1, int H2, int W2, int C) {
+  constexpr int RD = 2 * R + 1, NT = RD + 1;
+  constexpr int ROWS_PER_WAVE = (NT + ALT_WAVES - 1) / ALT_WAVES;
+  __shared__ __attribute__((aligned(16))) float f2s[(ALT_MAXPOS + 1) * ALT_PITCH];  // +1: zero row
+  __shared__ int bbox[4];
+  const int tid = threadIdx.x, q = tid & 63, wave = tid >> 6;
+  const int tiles_x = (W1 + ALT_TQ - 1) / ALT_TQ;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int n = blockIdx.y, b = blockIdx.z;
+  const int qx = tx * ALT_TQ + (q & 7), qy = ty * ALT_TQ + (q >> 3);
+  const bool qok = qx < W1 && qy < H1;
+  const int H1W1 = H1 * W1;
+  const int pix = qok ? qy * W1 + qx : 0;
+  const float* cp = coords + (((size_t)b * N + n) * H1W1 + pix) * 2;
+  const Bilin bl = bilin_setup(cp[0], cp[1], R);
+
+  if (tid < 4) bbox[tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;  // NT is even for every radius
+  __syncthreads();
+  if (qok && wave == 0) {
+    // windows that miss the plane completely contribute nothing and do not stretch the box
+    if (bl.x1 + NT > 0 && bl.x1 < W2 && bl.y1 + NT > 0 && bl.y1 < H2) {
+      atomicMin(&bbox[0], bl.x1);
+      atomicMin(&bbox[1], bl.y1);
+      atomicMax(&bbox[2], bl.x1 + NT);
+      atomicMax(&bbox[3], bl.y1 + NT);
+    }
+  }
+  __syncthreads();
+  const int bx0 = max(bbox[0], 0), by0 = max(bbox[1], 0);
+  const int bx1 = min(bbox[2], W2), by1 = min(bbox[3], H2);
+  const int RW = max(bx1 - bx0, 0), RH = max(by1 - by0, 0);
+  const int npos = RW * RH;
+  float* out = corr + (((size_t)b * N + n) * RD * RD) * H1W1 + pix;
+
+  if (npos > ALT_MAXPOS) {  // incoherent tile: per-query direct evaluation (same arithmetic order)
+    if (!qok) return;
+    const float* f1 = fmap1 + ((size_t)b * H1W1 + pix) * C;
+    const float* f2b = fmap2 + (size_t)b * H2 * W2 * C;
+    const float wnw = f32_value(bl.dy * bl.dx), wne = f32_value(bl.dy * (1.0f - bl.dx));
+    const float wsw = f32_value((1.0f - bl.dy) * bl.dx), wse = f32_value((1.0f - bl.dy) * (1.0f - bl.dx));
+    for (int o = wave; o < RD * RD; o += ALT_WAVES) {
+      const int ox = o / RD, oy = o % RD;
+      float s4[4];
+      for (int t = 0; t < 4; t++) {
+        const int h2 = bl.y1 + oy + (t >> 1), w2 = bl.x1 + ox + (t & 1);
+        float s = 0.f;
+        if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
+          const float* f2 = f2b + ((size_t)h2 * W2 + w2) * C;
+          for (int c = 0; c < C; c++) s = fmaf(f1[c], f2[c], s);
+        }
+        s4[t] = s;
+      }
+      float acc = s4[0] * wse;
+      acc = acc + s4[1] * wsw;
+      acc = acc + s4[2] * wne;
+      acc = acc + s4[3] * wnw;
+      out[(size_t)o * H1W1] = acc;
+    }
+    return;
+  }
+
+  // zero row for out-of-plane taps
+  if (tid < ALT_PITCH) f2s[ALT_MAXPOS * ALT_PITCH + tid] = 0.f;
+
+  float acc[ROWS_PER_WAVE][NT];
+#pragma unroll
+  for (int jr = 0; jr < ROWS_PER_WAVE; jr++)
+#pragma unroll
+    for (int i = 0; i < NT; i++) acc[jr][i] = 0.f;
+
+  // LDS offsets (in floats) of this thread's taps; ALT_MAXPOS = the zero row
+  int toff[ROWS_PER_WAVE][NT];
+#pragma unroll
+  for (int jr = 0; jr < ROWS_PER_WAVE; jr++) {
+    const int j = wave + ALT_WAVES * jr;
+    const int yy = bl.y1 + j - by0;
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+      const int xx = bl.x1 + i - bx0;
+      const bool ok = qok && j < NT && yy >= 0 && yy < RH && xx >= 0 && xx < RW;
+      toff[jr][i] = (ok ? yy * RW + xx : ALT_MAXPOS) * ALT_PITCH;
+    }
+  }
+
+  const float* f1p = fmap1 + ((size_t)b * H1W1 + pix) * C;
+  const float* f2b = fmap2 + (size_t)b * H2 * W2 * C;
+  for (int c0 = 0; c0 < C; c0 += ALT_CH) {
+    __syncthreads();  // previous chunk fully consumed
+    // this query's fmap1 chunk (in flight during the staging)
+    f4 a1[ALT_CH / 4];
+#pragma unroll
+    for (int k = 0; k < ALT_CH / 4; k++) a1[k] = *reinterpret_cast<const f4*>(f1p + c0 + 4 * k);
+    // stage fmap2[by0..by1, bx0..bx1, c0..c0+ALT_CH): (ALT_CH/4) threads x 16 B per position,
+    // four independent loads per thread in flight before the LDS stores
+    constexpr int TPP = ALT_CH / 4, PPI = ALT_THREADS / TPP;  // threads per position, positions per pass
+    for (int base = 0; base < npos; base += PPI * 4) {
+      f4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int p = base + u * PPI + tid / TPP;
+        if (p < npos) {
+          const int yy = p / RW, xx = p - yy * RW;
+          v[u] = *reinterpret_cast<const f4*>(f2b + ((size_t)(by0 + yy) * W2 + (bx0 + xx)) * C + c0 + 4 * (tid % TPP));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int p = base + u * PPI + tid / TPP;
+        if (p < npos) *reinterpret_cast<f4*>(&f2s[p * ALT_PITCH + 4 * (tid % TPP)]) = v[u];
+      }
+    }
+    __syncthreads();
+    // The loop is LDS-latency bound unless a whole tap (ALT_CH floats = 8 x 16-byte reads) is in
+    // flight while the previous tap is multiplied: explicit two-deep register pipeline over taps.
+    {
+      constexpr int NTAPS = ROWS_PER_WAVE * NT;
+      f4 wa[ALT_CH / 4], wb[ALT_CH / 4];
+#pragma unroll
+      for (int k = 0; k < ALT_CH / 4; k++) wa[k] = *reinterpret_cast<const f4*>(&f2s[toff[0][0] + 4 * k]);
+#pragma unroll
+      for (int tp = 0; tp < NTAPS; tp++) {
+        const int jr = tp / NT, i = tp % NT;
+        if (tp + 1 < NTAPS) {
+          const int jn = (tp + 1) / NT, in = (tp + 1) % NT;
+#pragma unroll
+          for (int k = 0; k < ALT_CH / 4; k++) {
+            const f4 v = *reinterpret_cast<const f4*>(&f2s[toff[jn][in] + 4 * k]);
+            if (tp & 1) wa[k] = v; else wb[k] = v;
+          }
+        }
+        float s0 = acc[jr][i], s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < ALT_CH / 4; k += 2) {
+          const f4 w0 = (tp & 1) ? wb[k] : wa[k];
+          const f4 w1 = (tp & 1) ? wb[k + 1] : wa[k + 1];
+          s0 = fmaf(a1[k][0], w0[0], s0);
+          s1 = fmaf(a1[k + 1][0], w1[0], s1);
+          s0 = fmaf(a1[k][1], w0[1], s0);
+          s1 = fmaf(a1[k + 1][1], w1[1], s1);
+          s0 = fmaf(a1[k][2], w0[2], s0);
+          s1 = fmaf(a1[k + 1][2], w1[2], s1);
+          s0 = fmaf(a1[k][3], w0[3], s0);
+          s1 = fmaf(a1[k + 1][3], w1[3], s1);
+        }
+        acc[jr][i] = s0 + s1;
+      }
+    }
+  }
+  __syncthreads();
+  // exchange the tap sums: taps[q][j][i], pitch NT*NT+1 to spread banks
+  constexpr int TP = NT * NT + 1;
+  float* taps = f2s;
+#pragma unroll
+  for (int jr = 0; jr < ROWS_PER_WAVE; jr++) {
+    const int j = wave + ALT_WAVES * jr;
+    if (j < NT) {
+#pragma unroll
+      for (int i = 0; i < NT; i++) taps[q * TP + j * NT + i] = acc[jr][i];
+    }
+  }
+  __syncthreads();
+  if (!qok) return;
+  const float wnw = f32_value(bl.dy * bl.dx), wne = f32_value(bl.dy * (1.0f - bl.dx));          // ak:119-122
+  const float wsw = f32_value((1.0f - bl.dy) * bl.dx), wse = f32_value((1.0f - bl.dy) * (1.0f - bl.dx));
+  for (int o = wave; o < RD * RD; o += ALT_WAVES) {
+    const int ox = o / RD, oy = o % RD;  // channel = ox*(2r+1) + oy
+    const float* tq = &taps[q * TP];
+    float v = tq[oy * NT + ox] * wse;                 // tap (iy=oy  , ix=ox  )
+    v = v + tq[oy * NT + ox + 1] * wsw;               // tap (oy  , ox+1)
+    v = v + tq[(oy + 1) * NT + ox] * wne;             // tap (oy+1, ox  )
+    v = v + tq[(oy + 1) * NT + ox + 1] * wnw;         // tap (oy+1, ox+1)
+    out[(size_t)o * H1W1] = v;
+  }
+}
+
 template <typename T>
 static int altcorr_forward_t(const void* f1, const void* f2, const float* coords, void* corr, int B,
                              int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s) {
@@ -316,6 +588,17 @@ int launch_altcorr_forward(const void* f1, const void* f2, const float* coords, 
                            int N, int H1, int W1, int H2, int W2, int C, int r, int dtype,
                            hipStream_t s) {
   if (B > 65535 || N > 65535) return DROID_E_ARG;
+  if (dtype == DROID_F32 && (C % ALT_CH) == 0 && (r == 3 || r == 4)) {
+    const int tiles = ((W1 + ALT_TQ - 1) / ALT_TQ) * ((H1 + ALT_TQ - 1) / ALT_TQ);
+    dim3 grid(tiles, N, B), block(ALT_THREADS);
+    if (r == 3)
+      hipLaunchKernelGGL((altcorr_forward_tiled<3>), grid, block, 0, s, static_cast<const float*>(f1),
+                         static_cast<const float*>(f2), coords, static_cast<float*>(corr), N, H1, W1, H2, W2, C);
+    else
+      hipLaunchKernelGGL((altcorr_forward_tiled<4>), grid, block, 0, s, static_cast<const float*>(f1),
+                         static_cast<const float*>(f2), coords, static_cast<float*>(corr), N, H1, W1, H2, W2, C);
+    return 0;
+  }
   switch (dtype) {
     case DROID_F16: return altcorr_forward_t<__half>(f1, f2, coords, corr, B, N, H1, W1, H2, W2, C, r, s);
     case DROID_F32: return altcorr_forward_t<float>(f1, f2, coords, corr, B, N, H1, W1, H2, W2, C, r, s);

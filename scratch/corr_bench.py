@@ -1,0 +1,47 @@
+import sys, os, json
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/droid-slam_reserch_amd")
+import numpy as np, torch, torch.nn.functional as F
+import droid_backends as db
+from droid_backends import synth
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dt = torch.float16 if (len(sys.argv) < 3 or sys.argv[2] == "f16") else torch.float32
+H, W, r = 48, 64, 3
+prob = synth.make_config("cfg2")
+fmaps, coords = synth.make_corr_inputs(prob, n_edges=B, seed=0)
+dev = "cuda"
+ii = torch.from_numpy(prob.ii[:B]).to(dev); jj = torch.from_numpy(prob.jj[:B]).to(dev)
+fm = torch.from_numpy(fmaps).to(dev)
+c = torch.from_numpy(coords).to(dev)
+pyr = []
+chunk = 32
+vols = [[] for _ in range(4)]
+for s in range(0, B, chunk):
+    f1 = (fm[ii[s:s+chunk]].float() / 4.0).reshape(-1, 128, H * W)
+    f2 = (fm[jj[s:s+chunk]].float() / 4.0).reshape(-1, 128, H * W)
+    vol = torch.matmul(f1.transpose(1, 2), f2).to(dt).reshape(-1, 1, H, W)
+    for lvl in range(4):
+        vols[lvl].append(vol.view(-1, H, W, H >> lvl, W >> lvl))
+        vol = F.avg_pool2d(vol.float(), 2, stride=2).to(dt)
+pyramid = [torch.cat(v, 0).contiguous() for v in vols]
+cq = c.permute(0, 3, 1, 2).contiguous()
+cl = [(cq / 2 ** l).contiguous() for l in range(4)]
+def run():
+    return [db.corr_index_forward(pyramid[l], cl[l], r)[0] for l in range(4)]
+run(); torch.cuda.synchronize()
+for l in range(4):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): db.corr_index_forward(pyramid[l], cl[l], r)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    es = pyramid[l].element_size()
+    alg = min(64, (H >> l) * (W >> l)) * es + 8 + 49 * es
+    print(f"level {l}: {ms*1e3:.1f} us  alg {B*H*W*alg/ms/1e6:.0f} GB/s  ({alg} B/pix)")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+es = pyramid[0].element_size()
+alg = sum(min(64, (H >> l) * (W >> l)) * es + 8 + 49 * es for l in range(4))
+print(f"all 4 levels B={B} {dt}: {ms*1e3:.1f} us  {B*H*W/ms/1e6:.2f} Gpix/s  alg {B*H*W*alg/ms/1e6:.0f} GB/s = {B*H*W*alg/ms/1e6/8000*100:.1f}% of 8 TB/s")
