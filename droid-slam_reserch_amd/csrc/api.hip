@@ -169,20 +169,20 @@ int droid_ba_build(const float* poses, const float* disps, const float* intrinsi
   return check_hip("ba_build");
 }
 
-int droid_ba_solve_update(float* poses, float* disps, const int64_t* ii, const int64_t* jj, int E,
-                          int nbuf, int H, int W, int M, int t0, int t1, float lm, float ep,
-                          int motion_only, float* dx_out, float* dz_out, void* workspace,
-                          size_t workspace_bytes, void* stream) {
-  (void)ii;
-  (void)jj;
+int droid_ba_solve_update(float* poses, float* disps, const float* intrinsics, const float* weights,
+                          const int64_t* ii, const int64_t* jj, int E, int nbuf, int H, int W, int M,
+                          int t0, int t1, float lm, float ep, int motion_only, float* dx_out,
+                          float* dz_out, void* workspace, size_t workspace_bytes, void* stream) {
   BaView v;
   int rc = ba_view(v, workspace, workspace_bytes, E, nbuf, H, W, t0, t1, M, motion_only);
   if (rc) return rc;
   if (!poses || !disps) return fail(DROID_E_ARG, "ba: null %s", "state pointer");
+  if (!motion_only && (!intrinsics || (E > 0 && (!weights || !ii || !jj))))
+    return fail(DROID_E_ARG, "ba: null %s", "intrinsics/weights/edges");
   hipStream_t s = (hipStream_t)stream;
   (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
   launch_chol_solve(v.sys, v.n, v.ld, (double)lm, (double)ep, v.xsol, v.hdr + HDR_CHOL_FAIL, s);
-  launch_update(v, poses, disps, v.xsol, dx_out, dz_out, motion_only != 0, s);
+  launch_update(v, poses, disps, intrinsics, weights, ii, jj, v.xsol, dx_out, dz_out, motion_only != 0, s);
   return check_hip("ba_solve_update");
 }
 
@@ -198,7 +198,7 @@ int droid_ba(float* poses, float* disps, const float* intrinsics, const float* d
     rc = droid_ba_build(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, E,
                         nbuf, H, W, M, t0, t1, motion_only, workspace, workspace_bytes, stream);
     if (rc) return rc;
-    rc = droid_ba_solve_update(poses, disps, ii, jj, E, nbuf, H, W, M, t0, t1, lm, ep, motion_only,
+    rc = droid_ba_solve_update(poses, disps, intrinsics, weights, ii, jj, E, nbuf, H, W, M, t0, t1, lm, ep, motion_only,
                                dx_out, dz_out, workspace, workspace_bytes, stream);
     if (rc) return rc;
   }
@@ -207,7 +207,7 @@ int droid_ba(float* poses, float* disps, const float* intrinsics, const float* d
 
 // Measurement support: one Gauss-Newton iteration (after droid_ba_prepare) with a HIP event
 // between kernel groups on `stream`; blocks until done.  stage_ms[8] = {memset+linearise,
-// assemble, schur SYRK, rhs Ev, damp+factor, back-substitution solve, dx/disps/poses update, total}.
+// assemble, fused E-rows + Schur SYRK + rhs, (unused), damp+factor, back-substitution solve, dx/disps/poses update, total}.
 int droid_ba_profile_iteration(float* poses, float* disps, const float* intrinsics,
                                const float* disps_sens, const float* targets, const float* weights,
                                const float* eta, const int64_t* ii, const int64_t* jj, int E,
@@ -235,7 +235,7 @@ int droid_ba_profile_iteration(float* poses, float* disps, const float* intrinsi
   (void)hipEventRecord(ev[5], s);
   launch_chol_backsolve(v.sys, v.n, v.ld, v.xsol, s);
   (void)hipEventRecord(ev[6], s);
-  launch_update(v, poses, disps, v.xsol, nullptr, nullptr, motion_only != 0, s);
+  launch_update(v, poses, disps, intrinsics, weights, ii, jj, v.xsol, nullptr, nullptr, motion_only != 0, s);
   (void)hipEventRecord(ev[7], s);
   hipError_t e = hipEventSynchronize(ev[7]);
   for (int k = 0; k < 7; k++) (void)hipEventElapsedTime(&stage_ms[k], ev[k], ev[k + 1]);

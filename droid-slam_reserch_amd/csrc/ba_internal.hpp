@@ -9,8 +9,6 @@ namespace droid {
 constexpr int LIN_THREADS = 256;
 constexpr int LIN_PPT = 4;                       // pixels per thread per chunk
 constexpr int LIN_CP = LIN_THREADS * LIN_PPT;    // pixels per workgroup chunk
-constexpr int SCHUR_KSPLIT = 4;                  // K (pixel) split of one SYRK tile
-constexpr int SCHUR_GRID = 2048;                 // workgroups of 4 waves, grid-stride over tiles
 constexpr int CHOL_NB = 64;                      // Cholesky block size
 
 enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4, HDR_WORDS = 16 };
@@ -74,7 +72,7 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.Hpart = static_cast<float*>(take(sizeof(float) * ((size_t)E * v.nch * 32 + 32)));
   v.Q = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
   v.w = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
-  v.Erows = static_cast<float*>(take(sizeof(float) * (M > 0 ? ((size_t)M + E) * 6 * v.HW + 4 : 4)));
+  v.Erows = nullptr;  // E rows are recomputed where they are consumed, never stored
   v.sys = static_cast<double*>(take(sizeof(double) * ((size_t)(v.n + 1) * v.ld + 8)));
   v.xsol = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld + 1)));
   v.dx = static_cast<float*>(take(sizeof(float) * ((size_t)v.n + 8)));
@@ -91,8 +89,9 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
                         const float* sens, const float* targets, const float* weights,
                         const float* eta, const int64_t* ii, const int64_t* jj, bool motion_only,
                         int stage, hipStream_t s);
-void launch_update(const BaView& v, float* poses, float* disps, const double* x, float* dx_out,
-                   float* dz_out, bool motion_only, hipStream_t s);
+void launch_update(const BaView& v, float* poses, float* disps, const float* intr, const float* weights,
+                   const int64_t* ii, const int64_t* jj, const double* x, float* dx_out, float* dz_out,
+                   bool motion_only, hipStream_t s);
 // In-place damped Cholesky of the lower triangle of sys (ld x ld, row n = rhs) + solve -> x [n].
 void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
                        hipStream_t s);

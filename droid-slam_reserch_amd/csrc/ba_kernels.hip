@@ -99,6 +99,53 @@ __device__ __forceinline__ int reduce32_index(int lane) {
          (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4);
 }
 
+// Per-edge metadata of one depth slot, resident in LDS for the lifetime of a workgroup, so that
+// the per-pixel loops never chase seg_edge -> jj -> poses through dependent global loads.
+constexpr int SLOT_MAXE = 128;  // edges per metadata chunk (slots with more are processed in chunks)
+struct SlotMeta {
+  int e[SLOT_MAXE];     // edge index
+  int pj[SLOT_MAXE];    // target pose index jj - t0 (may be outside [0,P))
+  int ent[SLOT_MAXE];   // Schur entry index of the edge within the slot, -1 if its target is not in the window
+  int flag[SLOT_MAXE];  // 1 = stereo pair (ii == jj)
+  float T[SLOT_MAXE][8];  // relative pose t[3], q[4]
+};
+
+// Loads edges [x0, x0+cnt) of slot m (cnt <= SLOT_MAXE) by the first cnt threads of the workgroup.
+// ent_base = entry index of the first window edge of this chunk.  Ends with a barrier.
+__device__ __forceinline__ void load_slot_meta(SlotMeta& sm, const BaView& v, const float* __restrict__ poses,
+                                               const int64_t* __restrict__ jj, int f, int x0, int cnt,
+                                               int ent_base) {
+  const int t = threadIdx.x;
+  if (t < cnt) {
+    const int e = v.seg_edge[x0 + t];
+    const int jx = (int)jj[e];
+    const Rel T = rel_pose<true>(poses, f, jx);
+    sm.e[t] = e;
+    sm.pj[t] = jx - v.t0;
+    sm.flag[t] = (jx == f) ? 1 : 0;
+#pragma unroll
+    for (int n = 0; n < 3; n++) sm.T[t][n] = T.t[n];
+#pragma unroll
+    for (int n = 0; n < 4; n++) sm.T[t][3 + n] = T.q[n];
+  }
+  __syncthreads();
+  if (t < cnt) {
+    int a = ent_base;
+    for (int u = 0; u < t; u++) a += (sm.pj[u] >= 0 && sm.pj[u] < v.P) ? 1 : 0;
+    sm.ent[t] = (sm.pj[t] >= 0 && sm.pj[t] < v.P) ? a : -1;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ Rel meta_rel(const SlotMeta& sm, int x) {
+  Rel T;
+#pragma unroll
+  for (int n = 0; n < 3; n++) T.t[n] = sm.T[x][n];
+#pragma unroll
+  for (int n = 0; n < 4; n++) T.q[n] = sm.T[x][3 + n];
+  return T;
+}
+
 // ------------------------------------------------------------------------------------------
 // prep: depth slots, CSR of edges by source frame, Schur entry lists and tile work list.
 // One workgroup; O(E + nbuf) work, run once per ba call (the graph is fixed across iterations).
@@ -251,6 +298,7 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
     const float* __restrict__ targets, const float* __restrict__ weights,
     const float* __restrict__ eta, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj) {
   __shared__ float red[2][LIN_THREADS / 64][32];
+  __shared__ SlotMeta sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HW = v.HW, W = v.W;
   const int chunk = blockIdx.y;
@@ -270,24 +318,35 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
   const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
 
   int pix[LIN_PPT];
-  float disp[LIN_PPT], Cacc[LIN_PPT], wacc[LIN_PPT], ei[LIN_PPT][6];
+  float disp[LIN_PPT], Cacc[LIN_PPT], wacc[LIN_PPT];
 #pragma unroll
   for (int p = 0; p < LIN_PPT; p++) {
     pix[p] = chunk * LIN_CP + p * LIN_THREADS + tid;
     Cacc[p] = 0.f;
     wacc[p] = 0.f;
-#pragma unroll
-    for (int n = 0; n < 6; n++) ei[p][n] = 0.f;
     disp[p] = 0.f;
     if (DEPTH && pix[p] < HW) disp[p] = disps[(size_t)f * HW + pix[p]];
   }
 
   int buf = 0;
   for (int x = xb; x < xe; x++) {
-    const int e = DEPTH ? v.seg_edge[x] : x;
-    const int ix = (int)ii[e], jx = (int)jj[e];
-    const Rel T = rel_pose<true>(poses, ix, jx);
-    const bool stereo = (ix == jx);
+    if (DEPTH && ((x - xb) % SLOT_MAXE) == 0) {  // (re)load the metadata chunk of this slot
+      if (x > xb) __syncthreads();
+      load_slot_meta(sm, v, poses, jj, f, x, min(SLOT_MAXE, xe - x), 0);
+    }
+    const int xl = DEPTH ? (x - xb) % SLOT_MAXE : 0;
+    const int e = DEPTH ? sm.e[xl] : x;
+    const int ix = DEPTH ? f : (int)ii[e];
+    Rel T;
+    bool stereo;
+    if (DEPTH) {
+      T = meta_rel(sm, xl);
+      stereo = sm.flag[xl] != 0;
+    } else {
+      const int jx = (int)jj[e];
+      T = rel_pose<true>(poses, ix, jx);
+      stereo = (ix == jx);
+    }
     float acc[32];
 #pragma unroll
     for (int k = 0; k < 32; k++) acc[k] = 0.f;
@@ -322,18 +381,6 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
           }
           acc[21 + a] += wa_u * L.ru + wa_v * L.rv;
         }
-        if (DEPTH) {
-          float eij[6], eii[6];
-          const float su = wu * L.Jzu, sv = wv * L.Jzv;
-#pragma unroll
-          for (int n = 0; n < 6; n++) eij[n] = su * L.Ju[n] + sv * L.Jv[n];  // dk:341, :374
-          float* er = v.Erows + ((size_t)(v.M + e) * 6) * HW + k;
-#pragma unroll
-          for (int n = 0; n < 6; n++) er[(size_t)n * HW] = eij[n];
-          adj_se3(T.t, T.q, eij, eii);  // Eii = -Adj^T Eij (linear in J), dk:325-326, :340
-#pragma unroll
-          for (int n = 0; n < 6; n++) ei[p][n] -= eii[n];
-        }
       }
     }
     // workgroup sum of the 27 block entries -> Hpart[e][chunk][0..31]
@@ -362,9 +409,6 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
         const float w = wacc[p] - ms * alpha * (disp[p] - sens);               // dk:1399
         v.Q[o] = 1.0f / C;                                                     // dk:1400
         v.w[o] = w;
-        float* er = v.Erows + ((size_t)m * 6) * HW + k;                        // dk:1402
-#pragma unroll
-        for (int n = 0; n < 6; n++) er[(size_t)n * HW] = ei[p][n];
       }
     }
   }
@@ -447,156 +491,360 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaView v, const float* 
 }
 
 // ------------------------------------------------------------------------------------------
-// Schur complement S = sum_slots B Q B^T on fp32 MFMA (EEt6x6_kernel :1001-1056 + the triple
-// enumeration of schur_block :1257-1272, as a batched SYRK).  One wave per work item =
-// (slot, lower 16x16 tile pair, K split); operands are read straight from the E rows in the
-// MFMA's own layout: lane l feeds row (l & 15), pixels 4*(l >> 4) .. +3 of each 16-pixel step
-// (one 16-byte load per operand per four v_mfma_f32_16x16x4_f32).
+// Schur complement + reduced rhs, fused with the E rows:
+//   S = sum_slots B Q B^T   (EEt6x6_kernel :1001-1056 + triple enumeration :1257-1272)
+//   b -= E Q w              (Ev6x1_kernel :1059-1093, update_rhs :1308)
+// The reference materialises E = [Ei; Eij] (:1402-1403, 166 MB at 2000 edges) and re-reads it per
+// triple.  Here one workgroup owns (depth slot, pixel range): for each 128-pixel tile it RECOMPUTES
+// the slot's E rows from weights / disparities / poses (the Jacobians are cheaper than the HBM
+// round trip), scales them by sqrt(Q) and parks them in LDS as B~ = B sqrt(Q) (so that
+// S = B~ B~^T needs no per-operand scaling), with one extra row w sqrt(Q) whose products with the
+// E rows are exactly E Q w.  The SYRK runs on v_mfma_f32_16x16x4_f32 out of LDS; accumulators
+// stay in registers over all pixel tiles of the range and are folded into the lower triangle of
+// the dense fp64 system with one atomic per entry.
+// Slots with more than 16 entries are processed in 96-row blocks (all block pairs), recomputing
+// the rows per pair, so any out-degree is handled with bounded LDS and registers.
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f32x4 load4_guard(const float* p, int k, int kend) {
-  f32x4 r = {0.f, 0.f, 0.f, 0.f};
-  if (p == nullptr) return r;
-  if (k + 3 < kend) {
-    r = *reinterpret_cast<const f32x4*>(p + k);
-  } else {
-    if (k < kend) r[0] = p[k];
-    if (k + 1 < kend) r[1] = p[k + 1];
-    if (k + 2 < kend) r[2] = p[k + 2];
+#ifdef SCHUR_STAMPS
+__device__ unsigned long long g_schur_stamps[8 * 16];
+#define SSTAMP(i) do { if (stamp_on) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_prev; st_prev = now_; } } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+
+constexpr int SF_TP = 64;             // pixels per LDS tile; 4 threads per pixel split the edges
+constexpr int SF_PITCH = SF_TP + 2;   // conflict-free b32 MFMA operand reads
+constexpr int SF_RB = 96;             // rows per block (16 entries)
+constexpr int SF_MAXT = 11;           // max 16x16 output tiles per wave: ceil(7*6/4)
+
+// E row (6 values, already scaled by `scale`) of one (edge, pixel)
+__device__ __forceinline__ void e_row(const Intr& K, const Rel& T, bool stereo, int k, int W, float disp,
+                                      float wu_raw, float wv_raw, float* eij) {
+  const PixLin L = linearize_pixel(K, T, (float)(k % W), (float)(k / W), disp, 0.f, 0.f);
+  float wu = L.valid * (0.001f * wu_raw), wv = L.valid * (0.001f * wv_raw);
+  if (stereo) {
+    wu = 0.f;
+    wv = 0.f;
   }
-  return r;
+  const float su = wu * L.Jzu, sv = wv * L.Jzv;
+#pragma unroll
+  for (int n = 0; n < 6; n++) eij[n] = su * L.Ju[n] + sv * L.Jv[n];  // dk:341, :374
 }
 
-__global__ __launch_bounds__(256) void ba_schur_kernel(BaView v) {
-  const int lane = threadIdx.x & 63;
-  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  const int M = min(v.hdr[HDR_M], v.M);
-  const int nwork = v.hdr[HDR_NWORK] * SCHUR_KSPLIT;
-  const int HW = v.HW, ld = v.ld;
-  const int kper = (((HW + SCHUR_KSPLIT - 1) / SCHUR_KSPLIT) + 15) & ~15;
-  for (int item = wave_global; item < nwork; item += nwaves) {
-    const int pair_g = item / SCHUR_KSPLIT, ks = item % SCHUR_KSPLIT;
-    // slot of this work item: last m with wk_ptr[m] <= pair_g
-    int lo = 0, hi = M;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (v.wk_ptr[mid] <= pair_g) lo = mid; else hi = mid;
-    }
-    const int m = lo;
-    int pr = pair_g - v.wk_ptr[m];
-    int ta = 0;
-    while (pr > ta) {
-      pr -= ta + 1;
-      ta++;
-    }
-    const int tb = pr;  // ta >= tb
-    const int e0 = v.ent_ptr[m];
-    const int R = 6 * (v.ent_ptr[m + 1] - e0);
-    const int ra = 16 * ta + (lane & 15), rb = 16 * tb + (lane & 15);
-    const float* pa = nullptr;
-    const float* pb = nullptr;
-    if (ra < R) pa = v.Erows + ((size_t)v.ent_row[e0 + ra / 6] * 6 + ra % 6) * HW;
-    if (rb < R) pb = v.Erows + ((size_t)v.ent_row[e0 + rb / 6] * 6 + rb % 6) * HW;
-    const float* q = v.Q + (size_t)m * HW;
-    const int kbeg = ks * kper, kend = min(HW, kbeg + kper);
-    if (kbeg >= kend) continue;
-    const int kg = 4 * (lane >> 4);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k = kbeg; k < kend; k += 16) {
-      const f32x4 a4 = load4_guard(pa, k + kg, kend);
-      const f32x4 b4 = load4_guard(pb, k + kg, kend);
-      const f32x4 q4 = load4_guard(q, k + kg, kend);
+__global__ __launch_bounds__(256) void ba_schur_fused_kernel(
+    BaView v, const float* __restrict__ poses, const float* __restrict__ disps,
+    const float* __restrict__ intrinsics, const float* __restrict__ weights,
+    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj) {
+  __shared__ float EA[(SF_RB + 16) * SF_PITCH];  // row block A (+ the w row, padded to a full tile)
+  __shared__ float EB[SF_RB * SF_PITCH];         // row block B (only for off-diagonal block pairs)
+  __shared__ float SP[4 * 6 * SF_TP];            // partial self rows of the four edge subsets
+  __shared__ SlotMeta sm;
+  const int m = blockIdx.x;
+  if (m >= min(v.hdr[HDR_M], v.M)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HW = v.HW, W = v.W;
+  const int e0 = v.ent_ptr[m], nent = v.ent_ptr[m + 1] - e0;
+  if (nent == 0) return;
+  const int R = 6 * nent;  // E rows; global row R is the w row
+  const int f = v.kx[m];
+  const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  // pixel range of this workgroup
+  const int tiles_total = (HW + SF_TP - 1) / SF_TP;
+  const int tpw = (tiles_total + gridDim.y - 1) / gridDim.y;
+  const int tile_beg = blockIdx.y * tpw, tile_end = min(tiles_total, tile_beg + tpw);
+  if (tile_beg >= tile_end) return;
+  const bool has_self = (v.ent_row[e0] < v.M);  // the self row, when present, is entry 0
+  const int nblk = (R + 1 + SF_RB - 1) / SF_RB;
+  const int pixl = tid & (SF_TP - 1), part = tid >> 6;  // four threads per pixel split the edges
+  const int x_beg = v.seg_ptr[m], nedges = v.seg_ptr[m + 1] - x_beg;
+  const bool resident = nedges <= SLOT_MAXE;  // the usual case: metadata loaded once
+  if (resident) load_slot_meta(sm, v, poses, jj, f, x_beg, nedges, has_self ? 1 : 0);
+
+  // software prefetch of the next tile's per-pixel inputs (Q, disparity, the weights of this
+  // thread's first four edges): issued before the MFMA phase of the current tile
+  constexpr int SF_PF = 4;
+  float pf_q = 0.f, pf_d = 0.f, pf_wr = 0.f, pf_w[2 * SF_PF];
+  auto prefetch = [&](int tile) {
+    const int k = tile * SF_TP + pixl;
+    const bool ok = (tile < tile_end) && (k < HW);
+    pf_q = ok ? v.Q[(size_t)m * HW + k] : 0.f;
+    pf_d = ok ? disps[(size_t)f * HW + k] : 0.f;
+    pf_wr = (ok && part == 0) ? v.w[(size_t)m * HW + k] : 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; s++)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s] * q4[s], b4[s], acc, 0, 0, 0);  // dk:1030-1038
+    for (int u = 0; u < SF_PF; u++) {
+      const int x = part + 4 * u;
+      const bool okx = ok && resident && x < nedges;
+      const float* wg = weights + (size_t)(okx ? sm.e[x] : 0) * 2 * HW;
+      pf_w[2 * u] = okx ? wg[k] : 0.f;
+      pf_w[2 * u + 1] = okx ? wg[HW + k] : 0.f;
     }
-    // D[i][j]: j = lane & 15, i = 4*(lane >> 4) + reg.  (A - S): subtract, lower triangle only.
-    const int lj = 16 * tb + (lane & 15);
+  };
+
+#ifdef SCHUR_STAMPS
+  const bool stamp_on = (lane == 0) && (blockIdx.x == 100) && (blockIdx.y == 1);
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
+  for (int ba = 0; ba < nblk; ba++) {
+    for (int bb = 0; bb <= ba; bb++) {
+      const int ra0 = ba * SF_RB, rb0 = bb * SF_RB;
+      const int na = min(SF_RB + ((ba == nblk - 1) ? 1 : 0), R + 1 - ra0);  // rows of block A (may include w)
+      const int nb = min(SF_RB, R - rb0);                                  // rows of block B (E rows only)
+      const int ta_n = (na + 15) / 16, tb_n = (nb + 15) / 16;
+      const int ntiles = (ba == bb) ? ta_n * (ta_n + 1) / 2 : ta_n * tb_n;
+      f32x4 acc[SF_MAXT];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int li = 16 * ta + 4 * (lane >> 4) + r;
-      if (li < R && lj < R) {
-        const int gi = 6 * v.ent_pose[e0 + li / 6] + li % 6;
-        const int gj = 6 * v.ent_pose[e0 + lj / 6] + lj % 6;
-        const double val = -(double)acc[r];
-        if (ta == tb) {  // both (li,lj) and (lj,li) are computed in a diagonal tile
-          if (gi >= gj) atomicAdd(&v.sys[(size_t)gi * ld + gj], val);
-        } else {  // the mirror element is not computed: fold it into the lower triangle
-          if (gi > gj) atomicAdd(&v.sys[(size_t)gi * ld + gj], val);
-          else if (gi < gj) atomicAdd(&v.sys[(size_t)gj * ld + gi], val);
-          else atomicAdd(&v.sys[(size_t)gi * ld + gj], 2.0 * val);
+      for (int t = 0; t < SF_MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+      prefetch(tile_beg);
+      for (int tile = tile_beg; tile < tile_end; tile++) {
+        const int k = tile * SF_TP + pixl;
+        const bool pok = k < HW;
+        const float cur_q = pf_q, cur_d = pf_d, cur_wr = pf_wr;
+        float cur_w[2 * SF_PF];
+#pragma unroll
+        for (int u = 0; u < 2 * SF_PF; u++) cur_w[u] = pf_w[u];
+        SSTAMP(0);
+        __syncthreads();  // previous tile consumed
+        SSTAMP(1);
+        // ---- stage: recompute the E rows of both blocks for 128 pixels
+        {
+          const float sq = sqrtf(cur_q);
+          const float disp = cur_d;
+          for (int side = 0; side < ((ba == bb) ? 1 : 2); side++) {
+            float* buf = side ? EB : EA;
+            const int r0 = side ? rb0 : ra0;
+            const int nrow = side ? nb : min(na, R - ra0);  // E rows in this block
+            const int a_beg = r0 / 6, a_end = (r0 + nrow + 5) / 6;  // entries touching the block
+            float selfacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const bool self_here = has_self && r0 == 0;
+            // edge entries of the block; when the self row lives here, every edge of the slot
+            // contributes to it (Ei = -sum_e Adj^T Eij, dk:325-326, :1402)
+            int ent_base = has_self ? 1 : 0;
+            for (int c0 = 0; c0 < nedges; c0 += SLOT_MAXE) {
+              const int cnt = min(SLOT_MAXE, nedges - c0);
+              if (!resident) {  // very high out-degree: stream the metadata in chunks
+                __syncthreads();
+                load_slot_meta(sm, v, poses, jj, f, x_beg + c0, cnt, ent_base);
+                for (int u = 0; u < cnt; u++) ent_base += (sm.ent[u] >= 0) ? 1 : 0;
+              }
+              for (int x = part; x < cnt; x += 4) {  // the four waves take the edges round-robin
+                const int a = sm.ent[x];
+                const bool in_blk = a >= a_beg && a < a_end;
+                if (!(in_blk || self_here)) continue;
+                const Rel T = meta_rel(sm, x);
+                float eij[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (pok) {
+                  float wu_raw, wv_raw;
+                  const int u = x >> 2;  // this thread's u-th edge
+                  if (resident && u < SF_PF) {
+                    wu_raw = cur_w[0];
+                    wv_raw = cur_w[1];
+#pragma unroll
+                    for (int uu = 1; uu < SF_PF; uu++)
+                      if (u == uu) {
+                        wu_raw = cur_w[2 * uu];
+                        wv_raw = cur_w[2 * uu + 1];
+                      }
+                  } else {
+                    const float* wg = weights + (size_t)sm.e[x] * 2 * HW;
+                    wu_raw = wg[k];
+                    wv_raw = wg[HW + k];
+                  }
+                  e_row(K, T, sm.flag[x] != 0, k, W, disp, wu_raw, wv_raw, eij);
+                }
+                if (self_here) {
+                  float eii[6];
+                  adj_se3(T.t, T.q, eij, eii);
+#pragma unroll
+                  for (int n = 0; n < 6; n++) selfacc[n] -= eii[n];
+                }
+                if (in_blk) {
+#pragma unroll
+                  for (int n = 0; n < 6; n++) {
+                    const int row = 6 * a + n - r0;
+                    if (row >= 0 && row < nrow) buf[row * SF_PITCH + pixl] = eij[n] * sq;
+                  }
+                }
+              }
+            }
+            SSTAMP(2);
+            if (self_here) {  // four partial sums per pixel, combined in a fixed order
+#pragma unroll
+              for (int n = 0; n < 6; n++) SP[(part * 6 + n) * SF_TP + pixl] = selfacc[n];
+              __syncthreads();
+              for (int n = part; n < 6; n += 4) {
+                const float sum = (SP[(0 * 6 + n) * SF_TP + pixl] + SP[(1 * 6 + n) * SF_TP + pixl]) +
+                                  (SP[(2 * 6 + n) * SF_TP + pixl] + SP[(3 * 6 + n) * SF_TP + pixl]);
+                buf[n * SF_PITCH + pixl] = sum * sq;
+              }
+              if (ba != bb) __syncthreads();  // SP is reused by the second side
+            }
+            // zero the padding rows up to the next multiple of 16 (and the w row slot)
+            const int rows_pad = ((side ? nb : na) + 15) & ~15;
+            for (int row = nrow + part; row < rows_pad; row += 4) buf[row * SF_PITCH + pixl] = 0.f;
+          }
+          if (ba == nblk - 1 && part == 0) {  // the w row: w sqrt(Q), global row R
+            EA[(R - ra0) * SF_PITCH + pixl] = cur_wr * sq;
+          }
+        }
+        SSTAMP(3);
+        __syncthreads();
+        SSTAMP(4);
+        prefetch(tile + 1);
+        // ---- SYRK of the tile: wave w owns output tiles w, w+4, ...
+        const int r = lane & 15, g = lane >> 4;
+        const float* Bs = (ba == bb) ? EA : EB;
+#pragma unroll
+        for (int t = 0; t < SF_MAXT; t++) {
+          const int ti = wave + 4 * t;
+          if (ti < ntiles) {
+            int ta, tb;
+            if (ba == bb) {
+              ta = 0;
+              int rem = ti;
+              while (rem > ta) {
+                rem -= ta + 1;
+                ta++;
+              }
+              tb = rem;
+            } else {
+              ta = ti / tb_n;
+              tb = ti % tb_n;
+            }
+            const float* pa = &EA[(16 * ta + r) * SF_PITCH + g];
+            const float* pb = &Bs[(16 * tb + r) * SF_PITCH + g];
+            f32x4 c = acc[t];
+#pragma unroll 8
+            for (int kk = 0; kk < SF_TP; kk += 4) c = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk], pb[kk], c, 0, 0, 0);
+            acc[t] = c;
+          }
         }
       }
+      SSTAMP(5);
+      // ---- fold the accumulators into the dense system (A - S): lower triangle, fp64 atomics
+      {
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < SF_MAXT; t++) {
+          const int ti = wave + 4 * t;
+          if (ti >= ntiles) continue;
+          int ta, tb;
+          if (ba == bb) {
+            ta = 0;
+            int rem = ti;
+            while (rem > ta) {
+              rem -= ta + 1;
+              ta++;
+            }
+            tb = rem;
+          } else {
+            ta = ti / tb_n;
+            tb = ti % tb_n;
+          }
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const int li = ra0 + 16 * ta + 4 * g + x;  // global row index within the slot (A side)
+            const int lj = rb0 + 16 * tb + r;          // B side, always an E row
+            if (lj >= R || li > R) continue;
+            const double val = -(double)acc[t][x];
+            const int gj = 6 * v.ent_pose[e0 + lj / 6] + lj % 6;
+            if (li == R) {  // w row: reduced rhs
+              atomicAdd(&v.sys[(size_t)v.n * v.ld + gj], val);
+              continue;
+            }
+            const int gi = 6 * v.ent_pose[e0 + li / 6] + li % 6;
+            const bool diag_tile = (ba == bb) && (ta == tb);
+            if (diag_tile) {  // both (li,lj) and (lj,li) are computed
+              if (gi >= gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
+            } else {  // the mirror element is not computed: fold it into the lower triangle
+              if (gi > gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
+              else if (gi < gj) atomicAdd(&v.sys[(size_t)gj * v.ld + gi], val);
+              else atomicAdd(&v.sys[(size_t)gi * v.ld + gj], 2.0 * val);
+            }
+          }
+        }
+      }
+      SSTAMP(6);
     }
   }
+#ifdef SCHUR_STAMPS
+  if (stamp_on)
+    for (int i = 0; i < 8; i++) g_schur_stamps[wave * 8 + i] = st_acc[i];
+#endif
 }
 
-// rhs of the reduced system: b -= E Q w  (Ev6x1_kernel :1059-1093, update_rhs :1308).
-// One workgroup per Schur entry.
-__global__ __launch_bounds__(256) void ba_ev_kernel(BaView v) {
-  __shared__ float red[4][8];
-  const int M = min(v.hdr[HDR_M], v.M);
-  const int nent = v.hdr[HDR_NENT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int ent = blockIdx.x; ent < nent; ent += gridDim.x) {
-    int lo = 0, hi = M;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (v.ent_ptr[mid] <= ent) lo = mid; else hi = mid;
-    }
-    const int m = lo;
-    const float* er = v.Erows + (size_t)v.ent_row[ent] * 6 * v.HW;
-    const float* q = v.Q + (size_t)m * v.HW;
-    const float* w = v.w + (size_t)m * v.HW;
-    float b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k = tid; k < v.HW; k += 256) {
-      const float qw = q[k] * w[k];
-#pragma unroll
-      for (int n = 0; n < 6; n++) b[n] += qw * er[(size_t)n * v.HW + k];
-    }
-#pragma unroll
-    for (int n = 0; n < 6; n++) {
-      float s = b[n];
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (lane == 0) red[wave][n] = s;
-    }
-    __syncthreads();
-    if (tid < 6) {
-      const double s = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
-      atomicAdd(&v.sys[(size_t)v.n * v.ld + 6 * v.ent_pose[ent] + tid], -s);
-    }
-    __syncthreads();
-  }
+#ifdef SCHUR_STAMPS
+extern "C" int droid_debug_schur_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_schur_stamps), sizeof(unsigned long long) * 8 * 16);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // depth back-substitution + disparity retraction: dz = Q (w - sum_entries E^T dx), disps += dz
 // (EvT6x1_kernel :1095-1115 incl. its `p <= 0` early return, accum + :1417, disp_retr :933-946).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_backsub_kernel(BaView v, float* __restrict__ disps,
-                                                          const float* __restrict__ dx,
-                                                          float* __restrict__ dz_out) {
+__global__ __launch_bounds__(256) void ba_backsub_kernel(
+    BaView v, const float* __restrict__ poses, float* __restrict__ disps,
+    const float* __restrict__ intrinsics, const float* __restrict__ weights,
+    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const float* __restrict__ dx,
+    float* __restrict__ dz_out) {
+  __shared__ SlotMeta sm;
   const int m = blockIdx.x;
   if (m >= min(v.hdr[HDR_M], v.M)) return;
   const int k = blockIdx.y * 256 + threadIdx.x;
-  if (k >= v.HW) return;
+  const bool pok = k < v.HW;
+  const int HW = v.HW;
   const int f = v.kx[m];
+  const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  const float disp = pok ? disps[(size_t)f * HW + k] : 0.f;
+  const int pf = f - v.t0;
+  // the self row exists for frames of the owned window (entry 0 of the slot) and feeds back
+  // only when its pose index is > 0 (dk:1105)
+  const int e0 = v.ent_ptr[m];
+  const bool has_self = (v.ent_ptr[m + 1] > e0) && (v.ent_row[e0] < v.M);
+  const bool self_on = has_self && pf > 0;
+  float dxi[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (self_on)
+    for (int n = 0; n < 6; n++) dxi[n] = dx[6 * pf + n];
   float acc = 0.f;
-  for (int ent = v.ent_ptr[m]; ent < v.ent_ptr[m + 1]; ent++) {
-    const int p = v.ent_pose[ent];
-    if (p <= 0) continue;  // dk:1105: the first window pose never feeds back into dz
-    const float* er = v.Erows + (size_t)v.ent_row[ent] * 6 * v.HW + k;
-    float dw = 0.f;
+  const int x_beg = v.seg_ptr[m], nedges = v.seg_ptr[m + 1] - x_beg;
+  for (int c0 = 0; c0 < nedges; c0 += SLOT_MAXE) {
+    const int cnt = min(SLOT_MAXE, nedges - c0);
+    if (c0 > 0) __syncthreads();
+    load_slot_meta(sm, v, poses, jj, f, x_beg + c0, cnt, 0);
+    if (!pok) continue;
+    for (int x = 0; x < cnt; x++) {
+      const int pj = sm.pj[x];
+      const bool edge_on = pj > 0 && pj < v.P;  // entries with p <= 0 or p >= P do not feed back
+      if (!(edge_on || self_on)) continue;
+      const Rel T = meta_rel(sm, x);
+      const float* wg = weights + (size_t)sm.e[x] * 2 * HW;
+      float eij[6];
+      e_row(K, T, sm.flag[x] != 0, k, v.W, disp, wg[k], wg[HW + k], eij);
+      if (edge_on) {
+        float dw = 0.f;
 #pragma unroll
-    for (int n = 0; n < 6; n++) dw += er[(size_t)n * v.HW] * dx[6 * p + n];
-    acc += dw;
+        for (int n = 0; n < 6; n++) dw += eij[n] * dx[6 * pj + n];
+        acc += dw;
+      }
+      if (self_on) {
+        float eii[6];
+        adj_se3(T.t, T.q, eij, eii);
+        float dw = 0.f;
+#pragma unroll
+        for (int n = 0; n < 6; n++) dw -= eii[n] * dxi[n];
+        acc += dw;
+      }
+    }
   }
-  const size_t o = (size_t)m * v.HW + k;
+  if (!pok) return;
+  const size_t o = (size_t)m * HW + k;
   const float dz = v.Q[o] * (v.w[o] - acc);
   if (dz_out) dz_out[o] = dz;
-  disps[(size_t)f * v.HW + k] += dz;
+  disps[(size_t)f * HW + k] = disp + dz;
 }
 
 // pose retraction T <- exp(dx) T for the window (pose_retr_kernel :898-931)
@@ -651,10 +899,16 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
         hipLaunchKernelGGL(ba_assemble_kernel, dim3(v.E), dim3(64), 0, s, v, poses, ii, jj);
       break;
     case 2:
-      if (depth) hipLaunchKernelGGL(ba_schur_kernel, dim3(SCHUR_GRID), dim3(256), 0, s, v);
+      if (depth) {
+        // pixel split so that small graphs still fill the chip (atomics grow with the split)
+        const int tiles = (v.HW + SF_TP - 1) / SF_TP;
+        int nsplit = 1024 / (v.M > 0 ? v.M : 1);
+        nsplit = nsplit < 1 ? 1 : (nsplit > tiles ? tiles : nsplit);
+        hipLaunchKernelGGL(ba_schur_fused_kernel, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps, intr,
+                           weights, ii, jj);
+      }
       break;
     case 3:
-      if (depth) hipLaunchKernelGGL(ba_ev_kernel, dim3(1024), dim3(256), 0, s, v);
       break;
   }
 }
@@ -666,13 +920,14 @@ void launch_build(const BaView& v, const float* poses, const float* disps, const
     launch_build_stage(v, poses, disps, intr, sens, targets, weights, eta, ii, jj, motion_only, stage, s);
 }
 
-void launch_update(const BaView& v, float* poses, float* disps, const double* x, float* dx_out,
-                   float* dz_out, bool motion_only, hipStream_t s) {
+void launch_update(const BaView& v, float* poses, float* disps, const float* intr, const float* weights,
+                   const int64_t* ii, const int64_t* jj, const double* x, float* dx_out, float* dz_out,
+                   bool motion_only, hipStream_t s) {
   hipLaunchKernelGGL(ba_finish_dx_kernel, dim3((v.n + 255) / 256), dim3(256), 0, s, v, x, v.dx,
                      dx_out);
   if (!motion_only && v.M > 0)
-    hipLaunchKernelGGL(ba_backsub_kernel, dim3(v.M, (v.HW + 255) / 256), dim3(256), 0, s, v, disps,
-                       v.dx, dz_out);
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3(v.M, (v.HW + 255) / 256), dim3(256), 0, s, v, poses, disps,
+                       intr, weights, ii, jj, v.dx, dz_out);
   hipLaunchKernelGGL(ba_pose_retr_kernel, dim3((v.P + 63) / 64), dim3(64), 0, s, poses, v.dx, v.t0,
                      v.t1);
 }

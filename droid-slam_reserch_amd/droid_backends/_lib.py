@@ -56,7 +56,7 @@ def load() -> ctypes.CDLL:
     lib.droid_ba.argtypes = [vp] * 9 + [c_int] * 8 + [c_float, c_float, c_int, vp, vp, vp, sz, vp]
     lib.droid_ba_prepare.argtypes = [vp, vp] + [c_int] * 10 + [vp, sz, vp]
     lib.droid_ba_build.argtypes = [vp] * 9 + [c_int] * 8 + [vp, sz, vp]
-    lib.droid_ba_solve_update.argtypes = [vp] * 4 + [c_int] * 7 + [c_float, c_float, c_int, vp, vp, vp, sz, vp]
+    lib.droid_ba_solve_update.argtypes = [vp] * 6 + [c_int] * 7 + [c_float, c_float, c_int, vp, vp, vp, sz, vp]
     lib.droid_ba_profile_iteration.argtypes = [vp] * 9 + [c_int] * 7 + [c_float, c_float, c_int, vp, sz, vp, vp]
     lib.droid_ba_system.argtypes = [vp] + [c_int] * 7 + [ctypes.POINTER(sz)]
     lib.droid_ba_system.restype = vp

@@ -104,8 +104,8 @@ class HipBackend:
     def solve_update(self, p: BAProblemDev, lm, ep, motion_only):
         E, nbuf, H, W, M, t0, t1 = self._dims
         s = torch.cuda.current_stream().cuda_stream
-        _lib.check(self.lib.droid_ba_solve_update(p.poses.data_ptr(), p.disps.data_ptr(), p.ii.data_ptr(),
-                                                  p.jj.data_ptr(), E, nbuf, H, W, M, t0, t1, float(lm), float(ep),
+        _lib.check(self.lib.droid_ba_solve_update(p.poses.data_ptr(), p.disps.data_ptr(), p.intrinsics.data_ptr(),
+                                                  p.weights.data_ptr(), p.ii.data_ptr(), p.jj.data_ptr(), E, nbuf, H, W, M, t0, t1, float(lm), float(ep),
                                                   int(motion_only), self.dx.data_ptr(),
                                                   self.dz.data_ptr() if M > 0 else None, self.ws.data_ptr(),
                                                   self.ws.numel(), s), "ba_solve_update")
@@ -121,7 +121,7 @@ class HipBackend:
             p.targets.data_ptr(), p.weights.data_ptr(), p.eta.data_ptr() if M > 0 else None, p.ii.data_ptr(),
             p.jj.data_ptr(), E, nbuf, H, W, M, t0, t1, float(lm), float(ep), int(motion_only),
             self.ws.data_ptr(), self.ws.numel(), s, ms), "ba_profile_iteration")
-        names = ["linearize", "assemble", "schur", "rhs", "factor", "backsolve", "update", "total"]
+        names = ["linearize", "assemble", "schur", "unused", "factor", "backsolve", "update", "total"]
         return dict(zip(names, [float(x) for x in ms]))
 
     def status(self):

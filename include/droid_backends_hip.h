@@ -97,7 +97,9 @@ int droid_ba(float *poses, float *disps, const float *intrinsics, const float *d
  *                   triangle valid, row 6P = rhs, no damping yet.  droid_ba_system() returns its device address so that the
  *                   caller can all-reduce (sum) it over ranks (RCCL) before the solve.
  * droid_ba_solve_update: damping (diag += ep + lm*diag), Cholesky, solve, depth
- *                   back-substitution for the owned slots, SE3 / disparity retraction.
+ *                   back-substitution for the owned slots (the E rows are recomputed from
+ *                   weights / disparities / the not yet retracted poses, never stored), SE3 /
+ *                   disparity retraction.
  */
 int droid_ba_prepare(const int64_t *ii, const int64_t *jj, int E, int nbuf, int H, int W, int M,
                      int t0, int t1, int own0, int own1, int motion_only, void *workspace,
@@ -109,14 +111,15 @@ int droid_ba_build(const float *poses, const float *disps, const float *intrinsi
                    int W, int M, int t0, int t1, int motion_only, void *workspace,
                    size_t workspace_bytes, void *stream);
 
-int droid_ba_solve_update(float *poses, float *disps, const int64_t *ii, const int64_t *jj, int E,
-                          int nbuf, int H, int W, int M, int t0, int t1, float lm, float ep,
-                          int motion_only, float *dx_out, float *dz_out, void *workspace,
-                          size_t workspace_bytes, void *stream);
+int droid_ba_solve_update(float *poses, float *disps, const float *intrinsics, const float *weights,
+                          const int64_t *ii, const int64_t *jj, int E, int nbuf, int H, int W, int M,
+                          int t0, int t1, float lm, float ep, int motion_only, float *dx_out,
+                          float *dz_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Measurement support (bench.py): one Gauss-Newton iteration after droid_ba_prepare with a HIP
  * event between kernel groups on `stream`; synchronises.  stage_ms[8] = {memset+linearise,
- * assemble, Schur SYRK, rhs, damp+Cholesky factor, triangular back-solve, state update, total}. */
+ * assemble, fused E-rows + Schur SYRK + rhs, (unused: 0), damp+Cholesky factor, triangular
+ * back-solve, state update, total}. */
 int droid_ba_profile_iteration(float *poses, float *disps, const float *intrinsics,
                                const float *disps_sens, const float *targets, const float *weights,
                                const float *eta, const int64_t *ii, const int64_t *jj, int E,
