@@ -181,7 +181,7 @@ int droid_ba_solve_update(float* poses, float* disps, const float* intrinsics, c
     return fail(DROID_E_ARG, "ba: null %s", "intrinsics/weights/edges");
   hipStream_t s = (hipStream_t)stream;
   (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
-  launch_chol_solve(v.sys, v.n, v.ld, (double)lm, (double)ep, v.xsol, v.hdr + HDR_CHOL_FAIL, s);
+  launch_chol_solve(v.sys, v.n, v.ld, (double)lm, (double)ep, v.xsol, v.hdr + HDR_CHOL_FAIL, v.bs_flags, s);
   launch_update(v, poses, disps, intrinsics, weights, ii, jj, v.xsol, dx_out, dz_out, motion_only != 0, s);
   return check_hip("ba_solve_update");
 }
@@ -233,7 +233,7 @@ int droid_ba_profile_iteration(float* poses, float* disps, const float* intrinsi
   (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
   launch_chol_factor(v.sys, v.n, v.ld, (double)lm, (double)ep, v.hdr + HDR_CHOL_FAIL, s);
   (void)hipEventRecord(ev[5], s);
-  launch_chol_backsolve(v.sys, v.n, v.ld, v.xsol, s);
+  launch_chol_backsolve(v.sys, v.n, v.ld, v.xsol, v.bs_flags, v.hdr + HDR_CHOL_FAIL, s);
   (void)hipEventRecord(ev[6], s);
   launch_update(v, poses, disps, intrinsics, weights, ii, jj, v.xsol, nullptr, nullptr, motion_only != 0, s);
   (void)hipEventRecord(ev[7], s);
@@ -278,7 +278,8 @@ int droid_chol_solve(const double* A, const double* b, double* x, int n, double*
   const int ld = (n + 1 + 7) & ~7;
   (void)hipMemsetAsync(fail_flag, 0, sizeof(int), s);
   launch_chol_pack(A, b, scratch, n, ld, s);
-  launch_chol_solve(scratch, n, ld, 0.0, 0.0, x, fail_flag, s);
+  int* flags = reinterpret_cast<int*>(scratch + (size_t)(n + 1) * ld);  // tail of the scratch buffer
+  launch_chol_solve(scratch, n, ld, 0.0, 0.0, x, fail_flag, flags, s);
   return check_hip("chol_solve");
 }
 

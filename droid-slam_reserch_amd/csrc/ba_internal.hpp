@@ -39,6 +39,7 @@ struct BaView {
   double* sys;             // [n+1][ld] reduced camera system, lower triangle, row n = rhs
   double* xsol;            // [ld] solve scratch / solution
   float* dx;               // [P][6]
+  int* bs_flags;           // [ceil(n/64)] hand-off flags of the backward substitution
 };
 
 struct BaSizes {
@@ -76,6 +77,7 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.sys = static_cast<double*>(take(sizeof(double) * ((size_t)(v.n + 1) * v.ld + 8)));
   v.xsol = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld + 1)));
   v.dx = static_cast<float*>(take(sizeof(float) * ((size_t)v.n + 8)));
+  v.bs_flags = static_cast<int*>(take(sizeof(int) * ((size_t)v.n / CHOL_NB + 2)));
   return off;
 }
 
@@ -93,11 +95,12 @@ void launch_update(const BaView& v, float* poses, float* disps, const float* int
                    const int64_t* ii, const int64_t* jj, const double* x, float* dx_out, float* dz_out,
                    bool motion_only, hipStream_t s);
 // In-place damped Cholesky of the lower triangle of sys (ld x ld, row n = rhs) + solve -> x [n].
+// flags: >= ceil(n/64) ints of scratch for the single-launch backward substitution (may be null)
 void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
-                       hipStream_t s);
+                       int* flags, hipStream_t s);
 
 void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag,
                         hipStream_t s);
-void launch_chol_backsolve(double* sys, int n, int ld, double* x, hipStream_t s);
+void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, int* err, hipStream_t s);
 
 }  // namespace droid

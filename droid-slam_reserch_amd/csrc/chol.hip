@@ -349,6 +349,110 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(double* __restrict_
   }
 }
 
+// Backward substitution as ONE launch: workgroup j owns block column j and consumes the
+// solutions x_k (k > j) of the workgroups to its right in exactly the order they are produced.
+// Wave 0 carries the dependent chain alone -- poll x_k, 64x64 mat-vec from LDS, finally the
+// 64-step solve -- while waves 1-3 prefetch the next off-diagonal tile L[k-1,j] into the other
+// LDS buffer; one workgroup barrier per block hands the tile over.
+// Hand-off: x itself is the flag.  x is pre-filled with an all-ones NaN pattern; the producer
+// publishes each x_j element with ONE 8-byte agent-scope (sc1) store and the consumer lanes poll
+// their own element with 8-byte agent-scope loads until it changes (single-copy atomic, so no
+// separate flag, fence or drain is needed; MI355X guide: data-tagged 8-byte granules).  The grid
+// is co-resident (<= BSP_MAX_BLOCKS workgroups, one per CU) and every spin is bounded.
+constexpr int BSP_MAX_BLOCKS = 200;
+constexpr long long BSP_SENTINEL = -1LL;
+
+// 64x64 tile -> LDS by the 192 threads of waves 1..3 (11 independent 16-byte loads per thread)
+__device__ __forceinline__ void load_tile64_w123(double* __restrict__ dst, const double* __restrict__ S,
+                                                 int ld, int r0, int c0, int row_end, int col_end) {
+  const int t = threadIdx.x - 64;
+  f64x2 v[11];
+#pragma unroll
+  for (int it = 0; it < 11; it++) {
+    const int idx2 = it * 192 + t;
+    const int i = idx2 >> 5, j = (idx2 & 31) * 2;
+    const bool ok = (idx2 < 2048) && (r0 + i < row_end) && (c0 + j < col_end);
+    const double* p = S + (size_t)(ok ? r0 + i : 0) * ld + (ok ? c0 + j : 0);
+    v[it] = *reinterpret_cast<const f64x2*>(p);
+    if (!ok) v[it] = (f64x2){0.0, 0.0};
+    else if (c0 + j + 1 >= col_end) v[it][1] = 0.0;
+  }
+#pragma unroll
+  for (int it = 0; it < 11; it++) {
+    const int idx2 = it * 192 + t;
+    if (idx2 < 2048) {
+      const int i = idx2 >> 5, j = (idx2 & 31) * 2;
+      *reinterpret_cast<f64x2*>(&dst[i * LDP + j]) = v[it];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
+    double* __restrict__ S, int n, int ld, double* __restrict__ x, int* __restrict__ err) {
+  __shared__ double Ld[NB * LDP];
+  __shared__ double Tt[2][NB * LDP];
+  __shared__ double xk[NB];
+  __shared__ int dead;
+  const int t = threadIdx.x;
+  const int nb = gridDim.x;
+  const int j = blockIdx.x;
+  const int c0 = j * NB;
+  const int wj = min(NB, n - c0);
+  if (t == 0) dead = 0;
+  load_tile64(Ld, S, ld, c0, c0, c0, c0 + wj, c0 + wj, true, 1.0);
+  double z = (t < wj) ? S[(size_t)n * ld + c0 + t] : 0.0;  // wave 0 owns z
+  int cur = 0;
+  if (j < nb - 1 && t >= 64) load_tile64_w123(Tt[0], S, ld, (nb - 1) * NB, c0, n, c0 + wj);
+  __syncthreads();
+  for (int k = nb - 1; k > j; k--) {
+    if (t >= 64) {
+      if (k - 1 > j) load_tile64_w123(Tt[cur ^ 1], S, ld, (k - 1) * NB, c0, n, c0 + wj);
+    } else {
+      // poll this lane's element of x_k (lanes beyond the matrix take 0)
+      const int gi = k * NB + t;
+      double xv = 0.0;
+      if (gi < n) {
+        int spins = 0;
+        while (true) {
+          xv = __hip_atomic_load(&x[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__double_as_longlong(xv) != BSP_SENTINEL) break;
+          if (++spins > (1 << 22)) {  // cannot happen with a resident grid; never hang the GPU
+            dead = 1;
+            atomicExch(err, 1);
+            xv = 0.0;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      xk[t] = xv;  // same wave writes and reads: LDS operations of one wave are ordered
+      const double* T = Tt[cur];
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+      for (int r = 0; r < NB; r += 4) {
+        a0 = fma(T[(r + 0) * LDP + t], xk[r + 0], a0);
+        a1 = fma(T[(r + 1) * LDP + t], xk[r + 1], a1);
+        a2 = fma(T[(r + 2) * LDP + t], xk[r + 2], a2);
+        a3 = fma(T[(r + 3) * LDP + t], xk[r + 3], a3);
+      }
+      z -= (a0 + a1) + (a2 + a3);
+    }
+    cur ^= 1;
+    __syncthreads();  // tile k-1 landed, tile k consumed
+    if (dead) return;
+  }
+  if (t < 64) {
+    const double rinv = 1.0 / Ld[t * LDP + t];
+#pragma unroll
+    for (int i = NB - 1; i >= 0; i--) {
+      const double xi = readlane_f64(z * rinv, i);
+      z = (t == i) ? xi : ((t < i) ? fma(-Ld[i * LDP + t], xi, z) : z);
+    }
+    if (__double_as_longlong(z) == BSP_SENTINEL) z = __longlong_as_double(0x7ff8000000000000LL);
+    if (t < wj) __hip_atomic_store(&x[c0 + t], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag,
                         hipStream_t s) {
   if (n <= 0) return;
@@ -360,8 +464,15 @@ void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* f
                        fail_flag);
 }
 
-void launch_chol_backsolve(double* sys, int n, int ld, double* x, hipStream_t s) {
+void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, int* err,
+                           hipStream_t s) {
   const int nb = (n + NB - 1) / NB;
+  if (flags != nullptr && nb >= 2 && nb <= BSP_MAX_BLOCKS) {
+    (void)flags;
+    (void)hipMemsetAsync(x, 0xFF, sizeof(double) * n, s);  // sentinel = "not yet published"
+    hipLaunchKernelGGL(chol_backsolve_persistent_kernel, dim3(nb), dim3(256), 0, s, sys, n, ld, x, err);
+    return;
+  }
   for (int k = nb - 1; k >= 0; k--) {
     const int c0 = k * NB;
     hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1 + (c0 + 255) / 256), dim3(256), 0, s, sys, n,
@@ -370,10 +481,10 @@ void launch_chol_backsolve(double* sys, int n, int ld, double* x, hipStream_t s)
 }
 
 void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
-                       hipStream_t s) {
+                       int* flags, hipStream_t s) {
   if (n <= 0) return;
   launch_chol_factor(sys, n, ld, lm, ep, fail_flag, s);
-  launch_chol_backsolve(sys, n, ld, x, s);
+  launch_chol_backsolve(sys, n, ld, x, flags, fail_flag, s);
 }
 
 // helper for droid_chol_solve: pack (A, b) into the augmented layout

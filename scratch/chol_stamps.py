@@ -7,7 +7,7 @@ rng = np.random.default_rng(0)
 A = rng.normal(size=(n, n + 8)); A = A @ A.T + n * 0.1 * np.eye(n); b = rng.normal(size=n)
 dA, dbb = torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()
 x = torch.zeros(n, dtype=torch.float64, device="cuda")
-scratch = torch.zeros((n + 1) * (n + 8) + 8, dtype=torch.float64, device="cuda")
+scratch = torch.zeros((n + 1) * (n + 8) + n // 64 + 16, dtype=torch.float64, device="cuda")
 flag = torch.zeros(1, dtype=torch.int32, device="cuda")
 vp = ctypes.c_void_p
 lib.droid_chol_solve.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp]
