@@ -40,7 +40,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void load_tile64(double* __restrict__ dst, const double* __restrict__ S,
                                             int ld, int r0, int c0, int row_begin, int row_end,
                                             int col_end, bool lower, double fill_diag) {
-  const int t = threadIdx.x;
+  const int t = threadIdx.x & 255;  // a 256-thread group (workgroups of 512 threads run two)
   f64x2 v[8];
 #pragma unroll
   for (int it = 0; it < 8; it++) {
@@ -74,7 +74,7 @@ __device__ __forceinline__ void load_tile64(double* __restrict__ dst, const doub
 __device__ __forceinline__ void store_tile64(double* __restrict__ S, const double* __restrict__ src,
                                              int ld, int r0, int c0, int row_begin, int row_end,
                                              int ncols, bool lower) {
-  const int t = threadIdx.x;
+  const int t = threadIdx.x & 255;
 #pragma unroll
   for (int it = 0; it < 16; it++) {
     const int idx = it * 256 + t;
@@ -167,30 +167,34 @@ __device__ __forceinline__ void wave_potrf16(double* Lb, double* Wl, int* fail, 
   if (lane == 0 && bad && report) *fail = 1;
 }
 
-// 64x64 tile update on one workgroup: acc (wave w: rows 16w..16w+15, all 64 columns) -= Lr Lc^T.
-__device__ __forceinline__ void tile_update64(f64x4 (&acc)[4], const double* Lr, const double* Lc) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// 16-row strip of a 64x64 tile update: acc[0..NN) (row group rg, column tiles nt0..nt0+NN) -= Lr Lc^T.
+template <int NN>
+__device__ __forceinline__ void strip_update(f64x4 (&acc)[4], const double* Lr, const double* Lc, int rg,
+                                             int nt0) {
+  const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
-  const double* Ar = &Lr[(16 * wave + r) * LDP + g];
+  const double* Ar = &Lr[(16 * rg + r) * LDP + g];
 #pragma unroll 4
   for (int kk = 0; kk < NB; kk += 4) {
     const double a = -Ar[kk];
 #pragma unroll
-    for (int nn = 0; nn < 4; nn++)
-      acc[nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lc[(16 * nn + r) * LDP + kk + g], acc[nn], 0, 0, 0);
+    for (int nn = 0; nn < NN; nn++)
+      acc[nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lc[(16 * (nt0 + nn) + r) * LDP + kk + g], acc[nn], 0, 0, 0);
   }
 }
 
-// accumulator fragment <-> global / LDS tile (row = 16*wave + (lane>>4) + 4i, col = 16nn + (lane&15))
+// accumulator fragment <- global: element i of tile nn is (row 16*rg + (lane>>4) + 4i, col 16*(nt0+nn) + (lane&15))
+template <int NN>
 __device__ __forceinline__ void frag_load_global(f64x4 (&acc)[4], const double* __restrict__ S, int ld,
-                                                 int r0, int q0, int row_end, int col_end, bool lower) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                 int r0, int q0, int rg, int nt0, int row_end, int col_end,
+                                                 bool lower) {
+  const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int nn = 0; nn < 4; nn++)
+  for (int nn = 0; nn < NN; nn++)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int li = 16 * wave + g + 4 * i, lj = 16 * nn + r;
+      const int li = 16 * rg + g + 4 * i, lj = 16 * (nt0 + nn) + r;
       const int row = r0 + li, col = q0 + lj;
       double v = 0.0;
       if (row < row_end && col < col_end && (!lower || lj <= li)) v = S[(size_t)row * ld + col];
@@ -198,112 +202,141 @@ __device__ __forceinline__ void frag_load_global(f64x4 (&acc)[4], const double* 
     }
 }
 
-__device__ __forceinline__ void frag_store_lds(const f64x4 (&acc)[4], double* T) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int nn = 0; nn < 4; nn++)
-#pragma unroll
-    for (int i = 0; i < 4; i++) T[(16 * wave + g + 4 * i) * LDP + 16 * nn + r] = acc[nn][i];
-}
-
-// One step of the blocked right-looking factorisation in ONE launch:
+// One step of the blocked right-looking factorisation in ONE launch of 512-thread workgroups:
 //   every tile (bi >= bj > k) of the trailing matrix:  A[bi,bj] -= L[bi,k] L[bj,k]^T
 //   tiles of block column k+1 additionally finish panel k+1: they rebuild and factor the updated
 //   diagonal tile A[k+1,k+1] (redundantly per workgroup: cheaper than a grid hand-off) and solve
 //   their own tile against it, so panel k+1 is ready when the launch ends.
 // k = -1 is the initial panel (no update).  Grid: (row blocks, column blocks) from k+1.
-__global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ S, int n, int ld, int k,
+//
+// Panel workgroups are organised around the pivot chain, which is the critical path:
+//   waves 0-3 ("D group") own the diagonal tile, waves 4-7 ("T group") the tile to be solved.
+//   * the D group updates the diagonal tile first; wave 0 then factors its 16x16 block (0,0)
+//     on the VALU while the T group's update of the own tile still runs on the matrix pipe;
+//   * per 16-column step p: {16x16 solves as GEMMs with the block inverse: one block per wave},
+//     then wave 0 updates block (p+1,p+1) and goes straight into its factorisation while waves
+//     1-7 apply the remaining rank-16 updates.
+__global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, int n, int ld, int k,
                                                         int* __restrict__ fail) {
-  __shared__ double B0[NB * LDP];   // L[bi,k], later the own tile T / X
-  __shared__ double B1[NB * LDP];   // L[bj,k], later the diagonal tile D / L
+  __shared__ double B0[NB * LDP];   // L[bi,k], later the tile being solved (T -> X)
+  __shared__ double B1[NB * LDP];   // L[bj,k]
+  __shared__ double B2[NB * LDP];   // the diagonal tile D -> L
   __shared__ double Wl[4 * 256];    // inverses of the four 16x16 diagonal blocks
   const int nrows = n + 1;          // row n = right-hand side
   const int kp = k + 1;             // block column being finished
   const int bi = kp + blockIdx.x, bj = kp + blockIdx.y;
   if (bj > bi) return;
-  const int t = threadIdx.x, wave = t >> 6;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int grp = wave >> 2, w4 = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
   const int r0 = bi * NB, q0 = bj * NB;
   const int c0 = kp * NB;                 // panel column
   const int wk = min(NB, n - c0);         // its width
   const bool panel = (bj == kp);
   const bool diag = panel && (bi == kp);
+  f64x4 acc[4];
 
-  f64x4 accT[4], accD[4];
-  // own tile (lower part only on the diagonal of the matrix) and, for panel workgroups, the
-  // diagonal tile of the panel column; both straight into MFMA accumulator layout
-  frag_load_global(accT, S, ld, r0, q0, nrows, n, bi == bj);
-  if (panel && !diag) frag_load_global(accD, S, ld, c0, c0, c0 + wk, c0 + wk, true);
-  if (k >= 0) {
+  if (!panel) {
+    // ---- plain trailing tile: wave = (row group w4, column tiles 2*grp, 2*grp+1)
+    if (k < 0) return;  // the initial panel has no update to apply
     const int p0 = k * NB;
-    load_tile64(B0, S, ld, r0, p0, r0, nrows, p0 + NB, false, 0.0);
-    if (!diag && bi != bj) load_tile64(B1, S, ld, q0, p0, q0, n, p0 + NB, false, 0.0);
+    frag_load_global<2>(acc, S, ld, r0, q0, w4, 2 * grp, nrows, n, bi == bj);
+    if (grp == 0) load_tile64(B0, S, ld, r0, p0, r0, nrows, p0 + NB, false, 0.0);
+    else if (bi != bj) load_tile64(B1, S, ld, q0, p0, q0, n, p0 + NB, false, 0.0);
     __syncthreads();
-    const double* Lc = (bi == bj) ? B0 : B1;
-    tile_update64(accT, B0, Lc);
-    if (panel && !diag) tile_update64(accD, B1, B1);
-    __syncthreads();
-  }
-  if (!panel) {  // plain trailing tile: write back
-    const int lane = t & 63, r = lane & 15, g = lane >> 4;
+    strip_update<2>(acc, B0, (bi == bj) ? B0 : B1, w4, 2 * grp);
 #pragma unroll
-    for (int nn = 0; nn < 4; nn++)
+    for (int nn = 0; nn < 2; nn++)
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const int li = 16 * wave + g + 4 * i, lj = 16 * nn + r;
+        const int li = 16 * w4 + fg + 4 * i, lj = 16 * (2 * grp + nn) + fr;
         const int row = r0 + li, col = q0 + lj;
-        if (row < nrows && col < n && (bi != bj || lj <= li)) S[(size_t)row * ld + col] = accT[nn][i];
+        if (row < nrows && col < n && (bi != bj || lj <= li)) S[(size_t)row * ld + col] = acc[nn][i];
       }
     return;
   }
 
-  // panel workgroup: B1 <- diagonal tile (identity-padded), B0 <- the rows to solve: the own tile,
-  // or for the diagonal workgroup the rows of its block below the diagonal tile (only the rhs row,
-  // and only when the last block column is narrower than NB)
+  // ---- panel workgroup
+  // rows to solve: the own tile, or for the diagonal workgroup the rows of its block below the
+  // diagonal tile (only the rhs row, and only when the last block column is narrower than NB)
   const bool solve_rows = !diag || (wk < NB);
-  frag_store_lds(diag ? accT : accD, B1);
-  if (solve_rows) frag_store_lds(accT, B0);
-  __syncthreads();
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int i = idx >> 6, j = idx & 63;
-    if (j > i) B1[i * LDP + j] = 0.0;  // strict upper part
-    else if (i >= wk || j >= wk) B1[i * LDP + j] = (i == j) ? 1.0 : 0.0;  // identity padding
-    if (diag && solve_rows && !(i >= wk && r0 + i < nrows && j < wk)) B0[i * LDP + j] = 0.0;
+  if (grp == 0) {
+    frag_load_global<4>(acc, S, ld, c0, c0, w4, 0, c0 + wk, c0 + wk, true);  // diagonal tile
+    if (k >= 0) load_tile64(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
+  } else {
+    frag_load_global<4>(acc, S, ld, r0, c0, w4, 0, nrows, n, diag);         // tile to solve
+    if (k >= 0) load_tile64(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
   }
+  __syncthreads();
+  if (k >= 0) {
+    if (grp == 0) strip_update<4>(acc, B1, B1, w4, 0);
+    else strip_update<4>(acc, B0, B1, w4, 0);
+  }
+  // fragments -> LDS with the final masking folded in.  Every wave writes only the 16 rows it
+  // alone has been reading (B0) or a buffer nobody reads yet (B2): no barrier needed before.
+#pragma unroll
+  for (int nn = 0; nn < 4; nn++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int li = 16 * w4 + fg + 4 * i, lj = 16 * nn + fr;
+      double val = acc[nn][i];
+      if (grp == 0) {  // diagonal tile: strict upper part 0, identity beyond wk
+        if (lj > li) val = 0.0;
+        else if (li >= wk || lj >= wk) val = (li == lj) ? 1.0 : 0.0;
+        B2[li * LDP + lj] = val;
+      } else {         // tile to solve; the diagonal workgroup keeps only the rows below the tile
+        if (diag && !(li >= wk && r0 + li < nrows && lj < wk)) val = 0.0;
+        B0[li * LDP + lj] = val;
+      }
+    }
+  // block (0,0) lives entirely in wave 0's fragments: factor it right away
+  if (wave == 0) wave_potrf16(&B2[0], &Wl[0], fail, diag);
   __syncthreads();
 
   for (int p = 0; p < 4; p++) {
-    if (wave == 0) wave_potrf16(&B1[(16 * p) * LDP + 16 * p], &Wl[256 * p], fail, diag);
-    __syncthreads();
-    {  // triangular solves as GEMMs with the block inverse: L_qp = D_qp W^T, X_gp = T_gp W^T
-      int cnt = 0;
-      for (int q = p + 1; q < 4; q++, cnt++)
-        if ((cnt & 3) == wave)
-          wave_gemm_nt16<true>(&B1[(16 * q) * LDP + 16 * p], &B1[(16 * q) * LDP + 16 * p], &Wl[256 * p], 16);
-      if (solve_rows)
-        for (int g = 0; g < 4; g++, cnt++)
-          if ((cnt & 3) == wave)
-            wave_gemm_nt16<true>(&B0[(16 * g) * LDP + 16 * p], &B0[(16 * g) * LDP + 16 * p], &Wl[256 * p], 16);
+    {  // 16x16 triangular solves as GEMMs with the block inverse: L_qp = D_qp W^T, X_gp = T_gp W^T
+      const int nd = 3 - p;  // diagonal-tile blocks below the pivot block
+      if (wave < nd) {
+        const int q = p + 1 + wave;
+        wave_gemm_nt16<true>(&B2[(16 * q) * LDP + 16 * p], &B2[(16 * q) * LDP + 16 * p], &Wl[256 * p], 16);
+      } else if (solve_rows && wave < nd + 4) {
+        const int g = wave - nd;
+        wave_gemm_nt16<true>(&B0[(16 * g) * LDP + 16 * p], &B0[(16 * g) * LDP + 16 * p], &Wl[256 * p], 16);
+      }
     }
     __syncthreads();
-    {  // trailing 16x16 blocks: D_rs -= L_rp L_sp^T (r >= s > p), T_gq -= X_gp L_qp^T (q > p)
+    if (p == 3) break;
+    if (wave == 0) {  // the pivot chain: next diagonal block, then its factorisation
+      const int q = p + 1;
+      wave_gemm_nt16<false>(&B2[(16 * q) * LDP + 16 * q], &B2[(16 * q) * LDP + 16 * p],
+                            &B2[(16 * q) * LDP + 16 * p], LDP);
+      wave_potrf16(&B2[(16 * q) * LDP + 16 * q], &Wl[256 * q], fail, diag);
+    } else {  // waves 1..7: the other rank-16 updates, round-robin
       int cnt = 0;
       for (int r = p + 1; r < 4; r++)
-        for (int s2 = p + 1; s2 <= r; s2++, cnt++)
-          if ((cnt & 3) == wave)
-            wave_gemm_nt16<false>(&B1[(16 * r) * LDP + 16 * s2], &B1[(16 * r) * LDP + 16 * p],
-                                  &B1[(16 * s2) * LDP + 16 * p], LDP);
+        for (int s2 = p + 1; s2 <= r; s2++) {
+          if (r == p + 1 && s2 == p + 1) continue;  // wave 0's block
+          if ((cnt % 7) + 1 == wave)
+            wave_gemm_nt16<false>(&B2[(16 * r) * LDP + 16 * s2], &B2[(16 * r) * LDP + 16 * p],
+                                  &B2[(16 * s2) * LDP + 16 * p], LDP);
+          cnt++;
+        }
       if (solve_rows)
         for (int g = 0; g < 4; g++)
-          for (int q = p + 1; q < 4; q++, cnt++)
-            if ((cnt & 3) == wave)
+          for (int q = p + 1; q < 4; q++) {
+            if ((cnt % 7) + 1 == wave)
               wave_gemm_nt16<false>(&B0[(16 * g) * LDP + 16 * q], &B0[(16 * g) * LDP + 16 * p],
-                                    &B1[(16 * q) * LDP + 16 * p], LDP);
+                                    &B2[(16 * q) * LDP + 16 * p], LDP);
+            cnt++;
+          }
     }
     __syncthreads();
   }
-  if (diag) store_tile64(S, B1, ld, c0, c0, c0, c0 + wk, wk, true);
-  if (solve_rows) store_tile64(S, B0, ld, r0, c0, max(r0, c0 + wk), min(r0 + NB, nrows), wk, false);
+  if (grp == 0) {
+    if (diag) store_tile64(S, B2, ld, c0, c0, c0, c0 + wk, wk, true);
+  } else if (solve_rows) {
+    store_tile64(S, B0, ld, r0, c0, max(r0, c0 + wk), min(r0 + NB, nrows), wk, false);
+  }
 }
 
 // One block column of the backward substitution L^T x = y (y = row n of S, consumed in place):
@@ -460,7 +493,7 @@ void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* f
   const int nb = (n + NB - 1) / NB;        // block columns
   const int nrb = (n + 1 + NB - 1) / NB;   // block rows (row n = rhs)
   for (int k = -1; k + 1 < nb; k++)         // launch k finishes panel k+1
-    hipLaunchKernelGGL(chol_step_kernel, dim3(nrb - k - 1, nb - k - 1), dim3(256), 0, s, sys, n, ld, k,
+    hipLaunchKernelGGL(chol_step_kernel, dim3(nrb - k - 1, k < 0 ? 1 : nb - k - 1), dim3(512), 0, s, sys, n, ld, k,
                        fail_flag);
 }
 
