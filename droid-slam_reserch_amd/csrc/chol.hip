@@ -25,6 +25,19 @@
 namespace droid {
 
 constexpr int NB = CHOL_NB;
+
+#ifdef CHOL_STAMPS
+// Diagnostic build only: s_memtime stamps of wave 0 of the first two panel workgroups.
+__device__ unsigned long long g_chol_stamps[64 * 16];
+#define STAMP(slot)                                                                         \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && panel && (blockIdx.x < 2)) {                                     \
+      g_chol_stamps[((k + 1) & 31) * 32 + blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    }                                                                                       \
+  } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
 constexpr int LDP = NB + 2;  // LDS row pitch in doubles: rows stay 16-B aligned, b64 MFMA operand reads conflict-free
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -111,8 +124,11 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // C(16x16) -= A(16x16) * B(16x16)^T on one wave.  A, C: LDS blocks with row pitch LDP; B: LDS
 // block with row pitch ldb.  v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4], B^T[l>>4][l&15];
 // result register i of lane l is D[(l>>4) + 4i][l&15].
+// NOT inlined on purpose: the panel path calls this from a dozen places, each executed once or
+// twice per workgroup; inlined, every call site is cold code and the instruction-cache misses cost
+// 4-5x the arithmetic (measured with s_memtime: 2.3-3.1k cycles cold vs 0.5k warm per call).
 template <bool ASSIGN>
-__device__ __forceinline__ void wave_gemm_nt16(double* C, const double* A, const double* B, int ldb) {
+__device__ __attribute__((noinline)) void wave_gemm_nt16(double* C, const double* A, const double* B, int ldb) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -134,6 +150,7 @@ __device__ __forceinline__ void wave_gemm_nt16(double* C, const double* A, const
 __device__ __forceinline__ void wave_potrf16(double* Lb, double* Wl, int* fail, bool report) {
   const int lane = threadIdx.x & 63, row = lane & 15;
   const bool ident = (lane & 16) != 0;
+  __builtin_amdgcn_s_setprio(3);  // the pivot chain outranks the MFMA waves sharing this SIMD
   double a[16];
 #pragma unroll
   for (int c = 0; c < 16; c++) {
@@ -165,6 +182,7 @@ __device__ __forceinline__ void wave_potrf16(double* Lb, double* Wl, int* fail, 
     for (int j = 0; j < 16; j++) Wl[j * 16 + row] = a[j];
   }
   if (lane == 0 && bad && report) *fail = 1;
+  __builtin_amdgcn_s_setprio(0);
 }
 
 // 16-row strip of a 64x64 tile update: acc[0..NN) (row group rg, column tiles nt0..nt0+NN) -= Lr Lc^T.
@@ -260,6 +278,7 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
   // rows to solve: the own tile, or for the diagonal workgroup the rows of its block below the
   // diagonal tile (only the rhs row, and only when the last block column is narrower than NB)
   const bool solve_rows = !diag || (wk < NB);
+  STAMP(0);
   if (grp == 0) {
     frag_load_global<4>(acc, S, ld, c0, c0, w4, 0, c0 + wk, c0 + wk, true);  // diagonal tile
     if (k >= 0) load_tile64(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
@@ -268,31 +287,45 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
     if (k >= 0) load_tile64(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
   }
   __syncthreads();
-  if (k >= 0) {
-    if (grp == 0) strip_update<4>(acc, B1, B1, w4, 0);
-    else strip_update<4>(acc, B0, B1, w4, 0);
-  }
-  // fragments -> LDS with the final masking folded in.  Every wave writes only the 16 rows it
-  // alone has been reading (B0) or a buffer nobody reads yet (B2): no barrier needed before.
+  STAMP(1);
+  // The diagonal tile gates the pivot chain, so the D group goes first and has the matrix pipe
+  // to itself; the T group's update then overlaps with wave 0's first 16x16 factorisation.
+  // Fragments go to LDS with the final masking folded in; every wave writes only rows it alone
+  // has been reading (B0) or a buffer nobody reads yet (B2).
+  if (grp == 0) {
+    if (k >= 0) strip_update<4>(acc, B1, B1, w4, 0);
 #pragma unroll
-  for (int nn = 0; nn < 4; nn++)
+    for (int nn = 0; nn < 4; nn++)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int li = 16 * w4 + fg + 4 * i, lj = 16 * nn + fr;
-      double val = acc[nn][i];
-      if (grp == 0) {  // diagonal tile: strict upper part 0, identity beyond wk
+      for (int i = 0; i < 4; i++) {  // diagonal tile: strict upper part 0, identity beyond wk
+        const int li = 16 * w4 + fg + 4 * i, lj = 16 * nn + fr;
+        double val = acc[nn][i];
         if (lj > li) val = 0.0;
         else if (li >= wk || lj >= wk) val = (li == lj) ? 1.0 : 0.0;
         B2[li * LDP + lj] = val;
-      } else {         // tile to solve; the diagonal workgroup keeps only the rows below the tile
+      }
+  }
+  if (k >= 0) __syncthreads();  // D group done with the matrix pipe
+  if (grp == 1) {
+    if (k >= 0) strip_update<4>(acc, B0, B1, w4, 0);
+#pragma unroll
+    for (int nn = 0; nn < 4; nn++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {  // tile to solve; the diagonal workgroup keeps only the rows below the tile
+        const int li = 16 * w4 + fg + 4 * i, lj = 16 * nn + fr;
+        double val = acc[nn][i];
         if (diag && !(li >= wk && r0 + li < nrows && lj < wk)) val = 0.0;
         B0[li * LDP + lj] = val;
       }
-    }
+  }
+  STAMP(2);
   // block (0,0) lives entirely in wave 0's fragments: factor it right away
   if (wave == 0) wave_potrf16(&B2[0], &Wl[0], fail, diag);
+  STAMP(3);
   __syncthreads();
+  STAMP(4);
 
+#pragma unroll 1  // one copy of the step body: iterations 1..3 then run from a warm instruction cache
   for (int p = 0; p < 4; p++) {
     {  // 16x16 triangular solves as GEMMs with the block inverse: L_qp = D_qp W^T, X_gp = T_gp W^T
       const int nd = 3 - p;  // diagonal-tile blocks below the pivot block
@@ -304,16 +337,29 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
         wave_gemm_nt16<true>(&B0[(16 * g) * LDP + 16 * p], &B0[(16 * g) * LDP + 16 * p], &Wl[256 * p], 16);
       }
     }
+    if (p == 0) STAMP(10);
+#ifdef CHOL_STAMPS
+    if (p == 0 && wave == 0) {  // warm repeat of the same call (result discarded into B1, unused by now)
+      for (int rep = 0; rep < 2; rep++) {
+        wave_gemm_nt16<true>(&B1[0], &B2[(16 * 1) * LDP], &Wl[0], 16);
+        STAMP(11 + rep);
+      }
+    }
+#endif
     __syncthreads();
+    if (p == 0) STAMP(5);
     if (p == 3) break;
     if (wave == 0) {  // the pivot chain: next diagonal block, then its factorisation
       const int q = p + 1;
       wave_gemm_nt16<false>(&B2[(16 * q) * LDP + 16 * q], &B2[(16 * q) * LDP + 16 * p],
                             &B2[(16 * q) * LDP + 16 * p], LDP);
       wave_potrf16(&B2[(16 * q) * LDP + 16 * q], &Wl[256 * q], fail, diag);
+      if (p == 0) STAMP(6);
     } else {  // waves 1..7: the other rank-16 updates, round-robin
       int cnt = 0;
+#pragma unroll 1
       for (int r = p + 1; r < 4; r++)
+#pragma unroll 1
         for (int s2 = p + 1; s2 <= r; s2++) {
           if (r == p + 1 && s2 == p + 1) continue;  // wave 0's block
           if ((cnt % 7) + 1 == wave)
@@ -322,7 +368,9 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
           cnt++;
         }
       if (solve_rows)
+#pragma unroll 1
         for (int g = 0; g < 4; g++)
+#pragma unroll 1
           for (int q = p + 1; q < 4; q++) {
             if ((cnt % 7) + 1 == wave)
               wave_gemm_nt16<false>(&B0[(16 * g) * LDP + 16 * q], &B0[(16 * g) * LDP + 16 * p],
@@ -331,12 +379,15 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
           }
     }
     __syncthreads();
+    if (p == 0) STAMP(7);
   }
+  STAMP(8);
   if (grp == 0) {
     if (diag) store_tile64(S, B2, ld, c0, c0, c0, c0 + wk, wk, true);
   } else if (solve_rows) {
     store_tile64(S, B0, ld, r0, c0, max(r0, c0 + wk), min(r0 + NB, nrows), wk, false);
   }
+  STAMP(9);
 }
 
 // One block column of the backward substitution L^T x = y (y = row n of S, consumed in place):
@@ -519,6 +570,12 @@ void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double*
   launch_chol_factor(sys, n, ld, lm, ep, fail_flag, s);
   launch_chol_backsolve(sys, n, ld, x, flags, fail_flag, s);
 }
+
+#ifdef CHOL_STAMPS
+extern "C" int droid_debug_chol_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_stamps), sizeof(unsigned long long) * 64 * 16);
+}
+#endif
 
 // helper for droid_chol_solve: pack (A, b) into the augmented layout
 __global__ void chol_pack_kernel(const double* __restrict__ A, const double* __restrict__ b,

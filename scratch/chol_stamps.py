@@ -18,8 +18,9 @@ print("err", np.abs(x.cpu().numpy() - np.linalg.solve(A, b)).max())
 buf = (ctypes.c_ulonglong * (64 * 16))()
 lib.droid_debug_chol_stamps(buf)
 st = np.array(buf[:], dtype=np.int64).reshape(32, 2, 16)
-names = ["load_issue->tiles_loaded", "update", "frag_store", "pad", "potrf0", "phases", "store"]
+labels = ["load", "updates+store", "potrf0", "barrier", "trsm0", "D11+potrf1", "trail0 barrier", "p=1..3", "store"]
 for kk in (1, 5, 12, 20):
     for wg in (0, 1):
-        d = np.diff(st[kk, wg, :7])
-        print(f"panel {kk} wg {wg} ({'diag' if wg == 0 else 'below'}):", " ".join(f"{nm}={v}" for nm, v in zip(["ld", "upd", "fst", "pad", "potrf0", "rest", "store"], d)), "total", st[kk, wg, 6] - st[kk, wg, 0])
+        d = np.diff(st[kk, wg, :10])
+        print("   trsm0 gemm of wave 0 alone:", st[kk, wg, 10] - st[kk, wg, 4], "repeat1", st[kk, wg, 11] - st[kk, wg, 10], "repeat2", st[kk, wg, 12] - st[kk, wg, 11])
+        print(f"panel {kk} wg {wg} ({'diag' if wg == 0 else 'below'}):", " ".join(f"{nm}={v}" for nm, v in zip(labels, d)), "total", st[kk, wg, 9] - st[kk, wg, 0])
