@@ -533,12 +533,16 @@ __device__ __forceinline__ void e_row(const Intr& K, const Rel& T, bool stereo, 
   for (int n = 0; n < 6; n++) eij[n] = su * L.Ju[n] + sv * L.Jv[n];  // dk:341, :374
 }
 
-__global__ __launch_bounds__(256) void ba_schur_fused_kernel(
+// MULTI = false: slots of at most 16 entries (one row block; no second LDS block, so three
+// workgroups fit a CU and one's VALU staging overlaps another's MFMA phase); MULTI = true: the
+// rest.  Both variants are launched; a workgroup whose slot belongs to the other one exits.
+template <bool MULTI>
+__global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
     BaView v, const float* __restrict__ poses, const float* __restrict__ disps,
     const float* __restrict__ intrinsics, const float* __restrict__ weights,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj) {
   __shared__ float EA[(SF_RB + 16) * SF_PITCH];  // row block A (+ the w row, padded to a full tile)
-  __shared__ float EB[SF_RB * SF_PITCH];         // row block B (only for off-diagonal block pairs)
+  __shared__ float EB[MULTI ? SF_RB * SF_PITCH : 4];  // row block B (only for off-diagonal block pairs)
   __shared__ float SP[4 * 6 * SF_TP];            // partial self rows of the four edge subsets
   __shared__ SlotMeta sm;
   const int m = blockIdx.x;
@@ -557,6 +561,7 @@ __global__ __launch_bounds__(256) void ba_schur_fused_kernel(
   if (tile_beg >= tile_end) return;
   const bool has_self = (v.ent_row[e0] < v.M);  // the self row, when present, is entry 0
   const int nblk = (R + 1 + SF_RB - 1) / SF_RB;
+  if (MULTI != (nblk > 1)) return;
   const int pixl = tid & (SF_TP - 1), part = tid >> 6;  // four threads per pixel split the edges
   const int x_beg = v.seg_ptr[m], nedges = v.seg_ptr[m + 1] - x_beg;
   const bool resident = nedges <= SLOT_MAXE;  // the usual case: metadata loaded once
@@ -594,9 +599,10 @@ __global__ __launch_bounds__(256) void ba_schur_fused_kernel(
       const int nb = min(SF_RB, R - rb0);                                  // rows of block B (E rows only)
       const int ta_n = (na + 15) / 16, tb_n = (nb + 15) / 16;
       const int ntiles = (ba == bb) ? ta_n * (ta_n + 1) / 2 : ta_n * tb_n;
-      f32x4 acc[SF_MAXT];
+      constexpr int MAXT = MULTI ? SF_MAXT : 7;  // one block: at most 7*8/2 = 28 tiles over 4 waves
+      f32x4 acc[MAXT];
 #pragma unroll
-      for (int t = 0; t < SF_MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
       prefetch(tile_beg);
       for (int tile = tile_beg; tile < tile_end; tile++) {
@@ -698,7 +704,7 @@ __global__ __launch_bounds__(256) void ba_schur_fused_kernel(
         const int r = lane & 15, g = lane >> 4;
         const float* Bs = (ba == bb) ? EA : EB;
 #pragma unroll
-        for (int t = 0; t < SF_MAXT; t++) {
+        for (int t = 0; t < MAXT; t++) {
           const int ti = wave + 4 * t;
           if (ti < ntiles) {
             int ta, tb;
@@ -728,7 +734,7 @@ __global__ __launch_bounds__(256) void ba_schur_fused_kernel(
       {
         const int r = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int t = 0; t < SF_MAXT; t++) {
+        for (int t = 0; t < MAXT; t++) {
           const int ti = wave + 4 * t;
           if (ti >= ntiles) continue;
           int ta, tb;
@@ -904,8 +910,10 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
         const int tiles = (v.HW + SF_TP - 1) / SF_TP;
         int nsplit = 1024 / (v.M > 0 ? v.M : 1);
         nsplit = nsplit < 1 ? 1 : (nsplit > tiles ? tiles : nsplit);
-        hipLaunchKernelGGL(ba_schur_fused_kernel, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps, intr,
-                           weights, ii, jj);
+        hipLaunchKernelGGL(ba_schur_fused_kernel<false>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
+                           intr, weights, ii, jj);
+        hipLaunchKernelGGL(ba_schur_fused_kernel<true>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
+                           intr, weights, ii, jj);
       }
       break;
     case 3:
