@@ -279,11 +279,19 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
   // diagonal tile (only the rhs row, and only when the last block column is narrower than NB)
   const bool solve_rows = !diag || (wk < NB);
   STAMP(0);
+  // T group: wave 4 shares its SIMD with wave 0 (the pivot chain, fp64 VALU) and therefore does no
+  // MFMA work; its row group 0 is split over waves 5,6,7 (column tiles {0,1}, {2}, {3}).
+  f64x4 accx[4];
+  const int x_nt0 = (wave == 5) ? 0 : (wave == 6 ? 2 : 3);
   if (grp == 0) {
     frag_load_global<4>(acc, S, ld, c0, c0, w4, 0, c0 + wk, c0 + wk, true);  // diagonal tile
     if (k >= 0) load_tile64(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
   } else {
-    frag_load_global<4>(acc, S, ld, r0, c0, w4, 0, nrows, n, diag);         // tile to solve
+    if (wave != 4) {
+      frag_load_global<4>(acc, S, ld, r0, c0, w4, 0, nrows, n, diag);       // tile to solve
+      if (wave == 5) frag_load_global<2>(accx, S, ld, r0, c0, 0, 0, nrows, n, diag);
+      else frag_load_global<1>(accx, S, ld, r0, c0, 0, x_nt0, nrows, n, diag);
+    }
     if (k >= 0) load_tile64(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
   }
   __syncthreads();
@@ -306,22 +314,36 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
       }
   }
   if (k >= 0) __syncthreads();  // D group done with the matrix pipe
-  if (grp == 1) {
-    if (k >= 0) strip_update<4>(acc, B0, B1, w4, 0);
+  auto store_solve = [&](const f64x4& a, int rg, int nt) {
 #pragma unroll
-    for (int nn = 0; nn < 4; nn++)
+    for (int i = 0; i < 4; i++) {  // tile to solve; the diagonal workgroup keeps only the rows below the tile
+      const int li = 16 * rg + fg + 4 * i, lj = 16 * nt + fr;
+      double val = a[i];
+      if (diag && !(li >= wk && r0 + li < nrows && lj < wk)) val = 0.0;
+      B0[li * LDP + lj] = val;
+    }
+  };
+  if (grp == 1 && wave != 4) {
+    if (k >= 0) {
+      strip_update<4>(acc, B0, B1, w4, 0);
+      if (wave == 5) strip_update<2>(accx, B0, B1, 0, 0);
+      else strip_update<1>(accx, B0, B1, 0, x_nt0);
+    }
 #pragma unroll
-      for (int i = 0; i < 4; i++) {  // tile to solve; the diagonal workgroup keeps only the rows below the tile
-        const int li = 16 * w4 + fg + 4 * i, lj = 16 * nn + fr;
-        double val = acc[nn][i];
-        if (diag && !(li >= wk && r0 + li < nrows && lj < wk)) val = 0.0;
-        B0[li * LDP + lj] = val;
-      }
+    for (int nn = 0; nn < 4; nn++) store_solve(acc[nn], w4, nn);  // rows only this wave has been reading
   }
   STAMP(2);
   // block (0,0) lives entirely in wave 0's fragments: factor it right away
   if (wave == 0) wave_potrf16(&B2[0], &Wl[0], fail, diag);
   STAMP(3);
+  __syncthreads();
+  // rows 0..15 of B0 were an MFMA operand of waves 5..7 until the barrier above
+  if (wave == 5) {
+    store_solve(accx[0], 0, 0);
+    store_solve(accx[1], 0, 1);
+  } else if (wave == 6 || wave == 7) {
+    store_solve(accx[0], 0, x_nt0);
+  }
   __syncthreads();
   STAMP(4);
 
