@@ -7,7 +7,7 @@
 namespace droid {
 
 constexpr int LIN_THREADS = 256;
-constexpr int LIN_PPT = 4;                       // pixels per thread per chunk
+constexpr int LIN_PPT = 2;                       // pixels per thread per chunk
 constexpr int LIN_CP = LIN_THREADS * LIN_PPT;    // pixels per workgroup chunk
 constexpr int CHOL_NB = 64;                      // Cholesky block size
 

@@ -328,6 +328,21 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
     if (DEPTH && pix[p] < HW) disp[p] = disps[(size_t)f * HW + pix[p]];
   }
 
+  float in_cur[LIN_PPT][4], in_nxt[LIN_PPT][4];  // target u,v and weight u,v of this thread's pixels
+  bool have_next = false;
+  auto fetch_edge = [&](int e, float (&dst)[LIN_PPT][4]) {
+    const float* tg = targets + (size_t)e * 2 * HW;
+    const float* wg = weights + (size_t)e * 2 * HW;
+#pragma unroll
+    for (int p = 0; p < LIN_PPT; p++) {
+      const bool ok = pix[p] < HW;
+      const int k = ok ? pix[p] : 0;
+      dst[p][0] = ok ? tg[k] : 0.f;
+      dst[p][1] = ok ? tg[HW + k] : 0.f;
+      dst[p][2] = ok ? wg[k] : 0.f;
+      dst[p][3] = ok ? wg[HW + k] : 0.f;
+    }
+  };
   int buf = 0;
   for (int x = xb; x < xe; x++) {
     if (DEPTH && ((x - xb) % SLOT_MAXE) == 0) {  // (re)load the metadata chunk of this slot
@@ -347,20 +362,31 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
       T = rel_pose<true>(poses, ix, jx);
       stereo = (ix == jx);
     }
+    // software pipeline: the next edge's targets / weights are in flight while this one is reduced
+    if (!have_next) fetch_edge(e, in_cur);
+    else {
+#pragma unroll
+      for (int p = 0; p < LIN_PPT; p++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) in_cur[p][c] = in_nxt[p][c];
+    }
+    have_next = false;
+    if (DEPTH && x + 1 < xe && xl + 1 < SLOT_MAXE) {
+      fetch_edge(sm.e[xl + 1], in_nxt);
+      have_next = true;
+    }
     float acc[32];
 #pragma unroll
     for (int k = 0; k < 32; k++) acc[k] = 0.f;
-    const float* tg = targets + (size_t)e * 2 * HW;
-    const float* wg = weights + (size_t)e * 2 * HW;
 #pragma unroll
     for (int p = 0; p < LIN_PPT; p++) {
       if (pix[p] < HW) {
         const int k = pix[p];
         const float d = DEPTH ? disp[p] : disps[(size_t)ix * HW + k];
         const float u = (float)(k % W), vv = (float)(k / W);
-        const PixLin L = linearize_pixel(K, T, u, vv, d, tg[k], tg[HW + k]);
-        float wu = L.valid * (0.001f * wg[k]);        // dk:305-306
-        float wv = L.valid * (0.001f * wg[HW + k]);
+        const PixLin L = linearize_pixel(K, T, u, vv, d, in_cur[p][0], in_cur[p][1]);
+        float wu = L.valid * (0.001f * in_cur[p][2]);        // dk:305-306
+        float wv = L.valid * (0.001f * in_cur[p][3]);
         if (DEPTH) {
           Cacc[p] += wu * L.Jzu * L.Jzu + wv * L.Jzv * L.Jzv;         // dk:320, :353
           wacc[p] += wu * L.ru * L.Jzu + wv * L.rv * L.Jzv;           // dk:321, :354
@@ -792,20 +818,28 @@ extern "C" int droid_debug_schur_stamps(unsigned long long* out) {
 // depth back-substitution + disparity retraction: dz = Q (w - sum_entries E^T dx), disps += dz
 // (EvT6x1_kernel :1095-1115 incl. its `p <= 0` early return, accum + :1417, disp_retr :933-946).
 // ------------------------------------------------------------------------------------------
+constexpr int BSUB_PPT = 1;  // pixels per thread: amortises the per-workgroup edge metadata
+
 __global__ __launch_bounds__(256) void ba_backsub_kernel(
     BaView v, const float* __restrict__ poses, float* __restrict__ disps,
     const float* __restrict__ intrinsics, const float* __restrict__ weights,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const float* __restrict__ dx,
     float* __restrict__ dz_out) {
   __shared__ SlotMeta sm;
+  __shared__ float dxs[SLOT_MAXE][6];  // dx of each edge's target pose (0 when it does not feed back)
   const int m = blockIdx.x;
   if (m >= min(v.hdr[HDR_M], v.M)) return;
-  const int k = blockIdx.y * 256 + threadIdx.x;
-  const bool pok = k < v.HW;
   const int HW = v.HW;
   const int f = v.kx[m];
   const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
-  const float disp = pok ? disps[(size_t)f * HW + k] : 0.f;
+  int kpix[BSUB_PPT];
+  float disp[BSUB_PPT], acc[BSUB_PPT];
+#pragma unroll
+  for (int p = 0; p < BSUB_PPT; p++) {
+    kpix[p] = (blockIdx.y * BSUB_PPT + p) * 256 + threadIdx.x;
+    disp[p] = kpix[p] < HW ? disps[(size_t)f * HW + kpix[p]] : 0.f;
+    acc[p] = 0.f;
+  }
   const int pf = f - v.t0;
   // the self row exists for frames of the owned window (entry 0 of the slot) and feeds back
   // only when its pose index is > 0 (dk:1105)
@@ -815,42 +849,55 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
   float dxi[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (self_on)
     for (int n = 0; n < 6; n++) dxi[n] = dx[6 * pf + n];
-  float acc = 0.f;
   const int x_beg = v.seg_ptr[m], nedges = v.seg_ptr[m + 1] - x_beg;
   for (int c0 = 0; c0 < nedges; c0 += SLOT_MAXE) {
     const int cnt = min(SLOT_MAXE, nedges - c0);
     if (c0 > 0) __syncthreads();
     load_slot_meta(sm, v, poses, jj, f, x_beg + c0, cnt, 0);
-    if (!pok) continue;
+    if (threadIdx.x < cnt) {
+      const int pj = sm.pj[threadIdx.x];
+      const bool on = pj > 0 && pj < v.P;  // entries with p <= 0 or p >= P do not feed back
+      for (int n = 0; n < 6; n++) dxs[threadIdx.x][n] = on ? dx[6 * pj + n] : 0.f;
+      sm.ent[threadIdx.x] = on ? 1 : 0;
+    }
+    __syncthreads();
     for (int x = 0; x < cnt; x++) {
-      const int pj = sm.pj[x];
-      const bool edge_on = pj > 0 && pj < v.P;  // entries with p <= 0 or p >= P do not feed back
+      const bool edge_on = sm.ent[x] != 0;
       if (!(edge_on || self_on)) continue;
       const Rel T = meta_rel(sm, x);
       const float* wg = weights + (size_t)sm.e[x] * 2 * HW;
-      float eij[6];
-      e_row(K, T, sm.flag[x] != 0, k, v.W, disp, wg[k], wg[HW + k], eij);
-      if (edge_on) {
-        float dw = 0.f;
+      float wraw[BSUB_PPT][2];
 #pragma unroll
-        for (int n = 0; n < 6; n++) dw += eij[n] * dx[6 * pj + n];
-        acc += dw;
+      for (int p = 0; p < BSUB_PPT; p++) {
+        const bool ok = kpix[p] < HW;
+        wraw[p][0] = ok ? wg[kpix[p]] : 0.f;
+        wraw[p][1] = ok ? wg[HW + kpix[p]] : 0.f;
       }
-      if (self_on) {
-        float eii[6];
-        adj_se3(T.t, T.q, eij, eii);
+#pragma unroll
+      for (int p = 0; p < BSUB_PPT; p++) {
+        float eij[6];
+        e_row(K, T, sm.flag[x] != 0, kpix[p] < HW ? kpix[p] : 0, v.W, disp[p], wraw[p][0], wraw[p][1], eij);
         float dw = 0.f;
 #pragma unroll
-        for (int n = 0; n < 6; n++) dw -= eii[n] * dxi[n];
-        acc += dw;
+        for (int n = 0; n < 6; n++) dw += eij[n] * dxs[x][n];
+        if (self_on) {
+          float eii[6];
+          adj_se3(T.t, T.q, eij, eii);
+#pragma unroll
+          for (int n = 0; n < 6; n++) dw -= eii[n] * dxi[n];
+        }
+        acc[p] += dw;
       }
     }
   }
-  if (!pok) return;
-  const size_t o = (size_t)m * HW + k;
-  const float dz = v.Q[o] * (v.w[o] - acc);
-  if (dz_out) dz_out[o] = dz;
-  disps[(size_t)f * HW + k] = disp + dz;
+#pragma unroll
+  for (int p = 0; p < BSUB_PPT; p++) {
+    if (kpix[p] >= HW) continue;
+    const size_t o = (size_t)m * HW + kpix[p];
+    const float dz = v.Q[o] * (v.w[o] - acc[p]);
+    if (dz_out) dz_out[o] = dz;
+    disps[(size_t)f * HW + kpix[p]] = disp[p] + dz;
+  }
 }
 
 // pose retraction T <- exp(dx) T for the window (pose_retr_kernel :898-931)
@@ -934,7 +981,7 @@ void launch_update(const BaView& v, float* poses, float* disps, const float* int
   hipLaunchKernelGGL(ba_finish_dx_kernel, dim3((v.n + 255) / 256), dim3(256), 0, s, v, x, v.dx,
                      dx_out);
   if (!motion_only && v.M > 0)
-    hipLaunchKernelGGL(ba_backsub_kernel, dim3(v.M, (v.HW + 255) / 256), dim3(256), 0, s, v, poses, disps,
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3(v.M, (v.HW + 256 * BSUB_PPT - 1) / (256 * BSUB_PPT)), dim3(256), 0, s, v, poses, disps,
                        intr, weights, ii, jj, v.dx, dz_out);
   hipLaunchKernelGGL(ba_pose_retr_kernel, dim3((v.P + 63) / 64), dim3(64), 0, s, poses, v.dx, v.t0,
                      v.t1);
