@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--keyframes", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-corr", action="store_true")
-    ap.add_argument("--corr-edges", type=int, default=64, help="edges per corr-lookup batch")
+    ap.add_argument("--corr-edges", type=int, default=256, help="edges per corr-lookup batch")
     return ap.parse_args()
 
 
@@ -140,13 +140,16 @@ def bench_corr(args, rank, world, dev, prob):
     fm = to_dev(fmaps, dev)  # [N,128,H,W] fp16
     c = to_dev(coords, dev)  # [B,H,W,2]
     # pyramid construction is the caller's (stock PyTorch, modules/corr.py:24-38), outside the timed region
-    f1 = (fm[ii].float() / 4.0).reshape(B, 128, H * W)
-    f2 = (fm[jj].float() / 4.0).reshape(B, 128, H * W)
-    vol = torch.matmul(f1.transpose(1, 2), f2).half().reshape(B * H * W, 1, H, W)
-    pyramid = []
-    for lvl in range(4):
-        pyramid.append(vol.view(B, H, W, H >> lvl, W >> lvl).contiguous())
-        vol = F.avg_pool2d(vol.float(), 2, stride=2).half()
+    vols = [[] for _ in range(4)]
+    for s0 in range(0, B, 32):  # all-pairs volume in chunks of 32 edges (fp32 matmul -> fp16, like autocast)
+        f1 = (fm[ii[s0:s0 + 32]].float() / 4.0).reshape(-1, 128, H * W)
+        f2 = (fm[jj[s0:s0 + 32]].float() / 4.0).reshape(-1, 128, H * W)
+        vol = torch.matmul(f1.transpose(1, 2), f2).half().reshape(-1, 1, H, W)
+        for lvl in range(4):
+            vols[lvl].append(vol.view(-1, H, W, H >> lvl, W >> lvl))
+            vol = F.avg_pool2d(vol.float(), 2, stride=2).half()
+    pyramid = [torch.cat(x, 0).contiguous() for x in vols]
+    del vols
     cq = c.permute(0, 3, 1, 2).contiguous()  # [B,2,H,W]
     cl = [(cq / 2 ** lvl).contiguous() for lvl in range(4)]
 
@@ -172,7 +175,7 @@ def bench_corr(args, rank, world, dev, prob):
                                 hbm_gbs=pix * vol_bytes_per_pix / ms_vol / 1e6,
                                 frac_of_8TBs=pix * vol_bytes_per_pix / ms_vol / 1e6 / HBM_PEAK_GBS))
     # alt-corr: channels-last fp32 pyramid of pooled fmaps (modules/corr.py:92-125)
-    Ba = min(B, 16)
+    Ba = min(B, 64)
     fml = fm.float() / 4.0
     pyr = []
     x = fml
@@ -197,21 +200,30 @@ def bench_corr(args, rank, world, dev, prob):
     return out
 
 
-def cpu_baseline(prob_small_iters=1):
-    """The oracle (CPU restatement of ba_cuda) timed on this box's host cores: cfg3, one iteration."""
+def cpu_baseline(budget_s=15.0):
+    """The oracle (CPU restatement of ba_cuda) timed on this box's host cores on the same 256-keyframe /
+    2000-edge graph: one iteration to calibrate, then as many as fit ~budget_s (at most the GPU run's 16)."""
     import oracle
     from droid_backends import synth
     oracle.build()
     p = synth.make_config("cfg3")
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    t0 = time.perf_counter()
-    oracle.ba(p.poses, p.disps, p.intrinsics, p.disps_sens, p.targets, p.weights, p.eta, p.ii, p.jj,
-              p.t0, p.t1, prob_small_iters, p.lm, p.ep, False)
-    dt = time.perf_counter() - t0
-    return dict(value=prob_small_iters / dt, unit="BA iters/s", cores=cores, kind="port",
-                sample=f"{prob_small_iters} Gauss-Newton iteration(s) of the full 256-keyframe/2000-edge 48x64 "
-                       f"graph, fp64 oracle (OpenMP over edges and depth frames), {dt:.1f} s")
+
+    def run(iters):
+        t0 = time.perf_counter()
+        oracle.ba(p.poses, p.disps, p.intrinsics, p.disps_sens, p.targets, p.weights, p.eta, p.ii, p.jj,
+                  p.t0, p.t1, iters, p.lm, p.ep, False)
+        return time.perf_counter() - t0
+
+    t1 = run(1)
+    iters, dt = 1, t1
+    more = int(min(16, budget_s / max(t1, 1e-3)))
+    if more >= 2:
+        iters, dt = more, run(more)
+    return dict(value=iters / dt, unit="BA iters/s", cores=cores, kind="port",
+                sample=f"{iters} Gauss-Newton iteration(s) of the full 256-keyframe/2000-edge 48x64 graph, "
+                       f"fp64 oracle (OpenMP over edges and depth frames), {dt:.1f} s")
 
 
 def main():
@@ -250,28 +262,54 @@ def main():
         K = args.steps
         raw = K / dt
         value = raw * (info["E"] / 2000.0)
-        # dominant kernel group of one iteration (HIP-event stage times)
-        dom = max((k for k in stages if k != "total"), key=lambda k: stages[k])
+        # ---- rooflines.  Durations: HIP events on the launch stream (stage_ms).  Algorithmic work:
+        # SURVEY.md section 8d.  `traffic`: FETCH_SIZE(x2, gfx950 wide-stream correction)+WRITE_SIZE per
+        # launch from the committed rocprofv3 --pmc passes of this same command (profiles/).
         HW, E_l, M_l, Nk, P = info["HW"], info["E_local"], info["M_local"], info["N"], info["P"]
         n = 6 * P
-        if dom in ("linearize", "schur", "rhs", "update", "assemble"):
-            # algorithmic (compulsory) bytes of one BA iteration, SURVEY.md section 8d
-            alg = 16.0 * E_l * HW + 16.0 * M_l * HW + 56.0 * Nk
-            roof = dict(kernel=dom, bound="hbm", achieved=alg / (stages[dom] * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
-                        unit="GB/s", traffic=None,
-                        note="algorithmic bytes of one BA iteration (16*E*HW + 16*M*HW + 56*N) / duration of the "
-                             "dominant kernel group")
-        else:
-            flops = n ** 3 / 3.0 if dom == "factor" else 2.0 * n * n
-            roof = dict(kernel=dom, bound="mfma", achieved=flops / (stages[dom] * 1e-3) / 1e12,
-                        peak=FP64_VEC_PEAK_TFLOPS, unit="TFLOP/s", traffic=None,
-                        note="fp64 Cholesky of the (6P)^2 reduced camera system: n^3/3 flops / duration; "
-                             "latency-bound chain of 2*ceil(n/64) launches, priced against the fp64 vector/MFMA peak")
-        roof["frac"] = roof["achieved"] / roof["peak"]
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        except Exception:
+            pass
+
+        def traffic(kernel):
+            k = pmc.get(kernel)
+            if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
+                return None
+            return (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
+
+        def hbm(kernel, stage, alg_bytes, note):
+            a = alg_bytes / (stages[stage] * 1e-3) / 1e9
+            return dict(kernel=kernel, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=a / HBM_PEAK_GBS, traffic=traffic(kernel), algorithmic_bytes=alg_bytes, note=note)
+
+        def flop(kernel, stage, flops, peak, note):
+            a = flops / (stages[stage] * 1e-3) / 1e12
+            return dict(kernel=kernel, bound="mfma", achieved=a, peak=peak, unit="TFLOP/s", frac=a / peak,
+                        traffic=traffic(kernel), algorithmic_flops=flops, note=note)
+
+        deg = np.bincount(prob.ii, minlength=Nk)  # Schur GEMM, symmetric minimum
+        nk = deg + 1
+        schur_flops = float(np.sum((6 * nk) * (6 * nk + 1) * HW + 6 * nk * HW)) * (E_l / max(1, len(prob.ii)))
+        kernels = [
+            flop("droid::chol_step_kernel", "factor", n ** 3 / 3.0, FP64_VEC_PEAK_TFLOPS,
+                 "fp64 Cholesky of the (6P)^2 reduced camera system, n^3/3 flops over ceil(n/64) dependent "
+                 "launches: a pivot-latency chain, priced against the fp64 vector/MFMA peak"),
+            hbm("droid::ba_lin_kernel<true>", "linearize", 16.0 * E_l * HW + 16.0 * M_l * HW + 56.0 * Nk,
+                "compulsory bytes of one BA iteration (16*E*HW + 16*M*HW + 56*N)"),
+            flop("droid::ba_schur_fused_kernel<false>", "schur", schur_flops, 157.3,
+                 "Schur SYRK, symmetric-minimum flops, fp32 MFMA peak; the kernel also recomputes the E rows"),
+            hbm("droid::ba_backsub_kernel", "update", 8.0 * E_l * HW + 16.0 * M_l * HW,
+                "weights (8*E*HW) + Q, w, disps r/w (16*M*HW)"),
+        ]
+        dom = max((k for k in stages if k not in ("total", "unused")), key=lambda k: stages[k])
+        stage_of = {"factor": 0, "linearize": 1, "schur": 2, "update": 3}
+        roof = dict(kernels[stage_of.get(dom, 0)])
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:
-                cpu = cpu_baseline(1)
+                cpu = cpu_baseline()
             except Exception as e:  # pragma: no cover
                 log("cpu baseline failed:", e)
         line = {
@@ -286,6 +324,7 @@ def main():
                        "ms_per_call_iterations2": info["call2_ms"], "stage_ms": stages,
                        "solve": "fp64 dense Cholesky on device", "chol_failed": info["chol_failed"]},
             "roofline": roof,
+            "rooflines": kernels,
             "cpu_baseline": cpu,
             "corr": corr,
         }
