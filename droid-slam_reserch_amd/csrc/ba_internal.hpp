@@ -31,7 +31,8 @@ struct BaView {
   int* ent_ptr;            // [nbuf+1] CSR of Schur entries by slot
   int* ent_row;            // [M+E] row of Erows
   int* ent_pose;           // [M+E] pose index in the window
-  int* wk_ptr;             // [nbuf+1] CSR of SYRK tile pairs by slot
+  int* wk_ptr;             // [nbuf+1] scratch (slot sizes while sorting)
+  int* order;              // [nbuf+1] slots sorted by descending edge count: big slots are dispatched first
   float* Hpart;            // [E][nch][32] per-(edge,chunk) partial Hjj (21) + vj (6)
   float* Q;                // [M][HW] 1/C
   float* w;                // [M][HW]
@@ -70,6 +71,7 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.ent_row = static_cast<int*>(take(sizeof(int) * ((size_t)M + E + 1)));
   v.ent_pose = static_cast<int*>(take(sizeof(int) * ((size_t)M + E + 1)));
   v.wk_ptr = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
+  v.order = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
   v.Hpart = static_cast<float*>(take(sizeof(float) * ((size_t)E * v.nch * 32 + 32)));
   v.Q = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
   v.w = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));

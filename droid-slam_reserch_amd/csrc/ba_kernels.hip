@@ -271,17 +271,20 @@ __global__ __launch_bounds__(1024) void ba_prep_kernel(BaView v, const int64_t* 
     }
   }
   __syncthreads();
-  // SYRK work list: lower-triangular 16x16 tile pairs of every slot's (6 r_m)^2 block
-  for (int m = t; m <= nbuf; m += T) v.wk_ptr[m] = 0;
+  // dispatch order: slots by descending edge count (ties by slot index), so that the heavy
+  // workgroups of the slot-parallel kernels start first (longest-processing-time-first packing)
+  for (int m = t; m < Ms; m += T) v.wk_ptr[m] = v.seg_ptr[m + 1] - v.seg_ptr[m];
   __syncthreads();
   for (int m = t; m < Ms; m += T) {
-    const int R = 6 * (v.ent_ptr[m + 1] - v.ent_ptr[m]);
-    const int RT = (R + 15) / 16;
-    v.wk_ptr[m] = RT * (RT + 1) / 2;
+    const int c = v.wk_ptr[m];
+    int rank = 0;
+    for (int u = 0; u < Ms; u++) {
+      const int cu = v.wk_ptr[u];
+      rank += (cu > c || (cu == c && u < m)) ? 1 : 0;
+    }
+    v.order[rank] = m;
   }
-  __syncthreads();
-  block_exscan(v.wk_ptr, nbuf + 1, lds, &tot);
-  if (t == 0) v.hdr[HDR_NWORK] = tot;
+  if (t == 0) v.hdr[HDR_NWORK] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -304,8 +307,8 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
   const int chunk = blockIdx.y;
   int xb, xe, f = -1, m = -1;
   if (DEPTH) {
-    m = blockIdx.x;
-    if (m >= min(v.hdr[HDR_M], v.M)) return;
+    if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
+    m = v.order[blockIdx.x];
     f = v.kx[m];
     xb = v.seg_ptr[m];
     xe = v.seg_ptr[m + 1];
@@ -571,8 +574,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
   __shared__ float EB[MULTI ? SF_RB * SF_PITCH : 4];  // row block B (only for off-diagonal block pairs)
   __shared__ float SP[4 * 6 * SF_TP];            // partial self rows of the four edge subsets
   __shared__ SlotMeta sm;
-  const int m = blockIdx.x;
-  if (m >= min(v.hdr[HDR_M], v.M)) return;
+  if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
+  const int m = v.order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HW = v.HW, W = v.W;
   const int e0 = v.ent_ptr[m], nent = v.ent_ptr[m + 1] - e0;
@@ -827,8 +830,8 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
     float* __restrict__ dz_out) {
   __shared__ SlotMeta sm;
   __shared__ float dxs[SLOT_MAXE][6];  // dx of each edge's target pose (0 when it does not feed back)
-  const int m = blockIdx.x;
-  if (m >= min(v.hdr[HDR_M], v.M)) return;
+  if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
+  const int m = v.order[blockIdx.x];
   const int HW = v.HW;
   const int f = v.kx[m];
   const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
