@@ -958,7 +958,7 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
       if (depth) {
         // pixel split so that small graphs still fill the chip (atomics grow with the split)
         const int tiles = (v.HW + SF_TP - 1) / SF_TP;
-        int nsplit = 1024 / (v.M > 0 ? v.M : 1);
+        int nsplit = 1536 / (v.M > 0 ? v.M : 1);
         nsplit = nsplit < 1 ? 1 : (nsplit > tiles ? tiles : nsplit);
         hipLaunchKernelGGL(ba_schur_fused_kernel<false>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
                            intr, weights, ii, jj);
