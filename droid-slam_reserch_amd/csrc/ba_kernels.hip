@@ -826,7 +826,7 @@ constexpr int BSUB_PPT = 1;  // pixels per thread: amortises the per-workgroup e
 __global__ __launch_bounds__(256) void ba_backsub_kernel(
     BaView v, const float* __restrict__ poses, float* __restrict__ disps,
     const float* __restrict__ intrinsics, const float* __restrict__ weights,
-    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const float* __restrict__ dx,
+    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const double* __restrict__ xsol,
     float* __restrict__ dz_out) {
   __shared__ SlotMeta sm;
   __shared__ float dxs[SLOT_MAXE][6];  // dx of each edge's target pose (0 when it does not feed back)
@@ -849,9 +849,11 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
   const int e0 = v.ent_ptr[m];
   const bool has_self = (v.ent_ptr[m + 1] > e0) && (v.ent_row[e0] < v.M);
   const bool self_on = has_self && pf > 0;
+  // dx = fp32(solution), or 0 when the factorisation failed (dk:1202-1210)
+  const bool failed = v.hdr[HDR_CHOL_FAIL] != 0;
   float dxi[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (self_on)
-    for (int n = 0; n < 6; n++) dxi[n] = dx[6 * pf + n];
+  if (self_on && !failed)
+    for (int n = 0; n < 6; n++) dxi[n] = (float)xsol[6 * pf + n];
   const int x_beg = v.seg_ptr[m], nedges = v.seg_ptr[m + 1] - x_beg;
   for (int c0 = 0; c0 < nedges; c0 += SLOT_MAXE) {
     const int cnt = min(SLOT_MAXE, nedges - c0);
@@ -860,7 +862,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
     if (threadIdx.x < cnt) {
       const int pj = sm.pj[threadIdx.x];
       const bool on = pj > 0 && pj < v.P;  // entries with p <= 0 or p >= P do not feed back
-      for (int n = 0; n < 6; n++) dxs[threadIdx.x][n] = on ? dx[6 * pj + n] : 0.f;
+      for (int n = 0; n < 6; n++) dxs[threadIdx.x][n] = (on && !failed) ? (float)xsol[6 * pj + n] : 0.f;
       sm.ent[threadIdx.x] = on ? 1 : 0;
     }
     __syncthreads();
@@ -903,29 +905,26 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
   }
 }
 
-// pose retraction T <- exp(dx) T for the window (pose_retr_kernel :898-931)
-__global__ void ba_pose_retr_kernel(float* __restrict__ poses, const float* __restrict__ dx, int t0,
-                                    int t1) {
-  const int k = t0 + blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= t1) return;
+// pose retraction T <- exp(dx) T for the window (pose_retr_kernel :898-931); dx = fp32 of the fp64
+// solution, zeros when the factorisation failed (:1202-1210)
+__global__ void ba_pose_retr_kernel(BaView v, float* __restrict__ poses, const double* __restrict__ xsol,
+                                    float* __restrict__ dx_out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool failed = v.hdr[HDR_CHOL_FAIL] != 0;
+  if (p == 0 && failed) atomicOr(&v.hdr[HDR_STATUS], STATUS_CHOL_FAIL);
+  if (p >= v.P) return;
+  const int k = v.t0 + p;
   float xi[6], t[3], q[4], tn[3], qn[4];
-  for (int n = 0; n < 6; n++) xi[n] = dx[6 * (k - t0) + n];
+  for (int n = 0; n < 6; n++) {
+    xi[n] = failed ? 0.f : (float)xsol[6 * p + n];
+    v.dx[6 * p + n] = xi[n];
+    if (dx_out) dx_out[6 * p + n] = xi[n];
+  }
   for (int n = 0; n < 3; n++) t[n] = poses[7 * k + n];
   for (int n = 0; n < 4; n++) q[n] = poses[7 * k + 3 + n];
   retr_se3(xi, t, q, tn, qn);
   for (int n = 0; n < 3; n++) poses[7 * k + n] = tn[n];
   for (int n = 0; n < 4; n++) poses[7 * k + 3 + n] = qn[n];
-}
-
-// x (fp64 solution) -> dx (fp32), zeros when the factorisation failed (:1202-1210)
-__global__ void ba_finish_dx_kernel(BaView v, const double* __restrict__ x, float* __restrict__ dx,
-                                    float* __restrict__ dx_out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && v.hdr[HDR_CHOL_FAIL]) atomicOr(&v.hdr[HDR_STATUS], STATUS_CHOL_FAIL);
-  if (i >= v.n) return;
-  const float val = v.hdr[HDR_CHOL_FAIL] ? 0.f : (float)x[i];
-  dx[i] = val;
-  if (dx_out) dx_out[i] = val;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -981,13 +980,10 @@ void launch_build(const BaView& v, const float* poses, const float* disps, const
 void launch_update(const BaView& v, float* poses, float* disps, const float* intr, const float* weights,
                    const int64_t* ii, const int64_t* jj, const double* x, float* dx_out, float* dz_out,
                    bool motion_only, hipStream_t s) {
-  hipLaunchKernelGGL(ba_finish_dx_kernel, dim3((v.n + 255) / 256), dim3(256), 0, s, v, x, v.dx,
-                     dx_out);
   if (!motion_only && v.M > 0)
     hipLaunchKernelGGL(ba_backsub_kernel, dim3(v.M, (v.HW + 256 * BSUB_PPT - 1) / (256 * BSUB_PPT)), dim3(256), 0, s, v, poses, disps,
-                       intr, weights, ii, jj, v.dx, dz_out);
-  hipLaunchKernelGGL(ba_pose_retr_kernel, dim3((v.P + 63) / 64), dim3(64), 0, s, poses, v.dx, v.t0,
-                     v.t1);
+                       intr, weights, ii, jj, x, dz_out);
+  hipLaunchKernelGGL(ba_pose_retr_kernel, dim3((v.P + 63) / 64), dim3(64), 0, s, v, poses, x, dx_out);
 }
 
 }  // namespace droid

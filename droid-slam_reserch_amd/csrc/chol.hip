@@ -97,14 +97,6 @@ __device__ __forceinline__ void store_tile64(double* __restrict__ S, const doubl
   }
 }
 
-__global__ void chol_damp_kernel(double* __restrict__ S, int n, int ld, double lm, double ep) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const double d = S[(size_t)i * ld + i];
-    S[(size_t)i * ld + i] = d + (ep + lm * d);
-  }
-}
-
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -235,7 +227,7 @@ __device__ __forceinline__ void frag_load_global(f64x4 (&acc)[4], const double* 
 //     then wave 0 updates block (p+1,p+1) and goes straight into its factorisation while waves
 //     1-7 apply the remaining rank-16 updates.
 __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, int n, int ld, int k,
-                                                        int* __restrict__ fail) {
+                                                        int* __restrict__ fail, double lm, double ep) {
   __shared__ double B0[NB * LDP];   // L[bi,k], later the tile being solved (T -> X)
   __shared__ double B1[NB * LDP];   // L[bj,k]
   __shared__ double B2[NB * LDP];   // the diagonal tile D -> L
@@ -256,7 +248,16 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
 
   if (!panel) {
     // ---- plain trailing tile: wave = (row group w4, column tiles 2*grp, 2*grp+1)
-    if (k < 0) return;  // the initial panel has no update to apply
+    if (k < 0) {
+      // initial launch: the spare workgroups of block column 1 apply the damping diag += ep + lm*diag
+      // (SparseBlock::solve, dk:1197) to the rows below the first block; block 0 is damped on load
+      const int i = r0 + t;
+      if (bj == kp + 1 && t < NB && i >= NB && i < n) {
+        const double d = S[(size_t)i * ld + i];
+        S[(size_t)i * ld + i] = d + (ep + lm * d);
+      }
+      return;
+    }
     const int p0 = k * NB;
     frag_load_global<2>(acc, S, ld, r0, q0, w4, 2 * grp, nrows, n, bi == bj);
     if (grp == 0) load_tile64(B0, S, ld, r0, p0, r0, nrows, p0 + NB, false, 0.0);
@@ -285,6 +286,13 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
   const int x_nt0 = (wave == 5) ? 0 : (wave == 6 ? 2 : 3);
   if (grp == 0) {
     frag_load_global<4>(acc, S, ld, c0, c0, w4, 0, c0 + wk, c0 + wk, true);  // diagonal tile
+    if (k < 0) {  // damping of block 0, applied to every workgroup's private copy
+#pragma unroll
+      for (int nn = 0; nn < 4; nn++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (16 * w4 + fg + 4 * i == 16 * nn + fr) acc[nn][i] += ep + lm * acc[nn][i];
+    }
     if (k >= 0) load_tile64(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
   } else {
     if (wave != 4) {
@@ -562,12 +570,11 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
 void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag,
                         hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(chol_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sys, n, ld, lm, ep);
   const int nb = (n + NB - 1) / NB;        // block columns
   const int nrb = (n + 1 + NB - 1) / NB;   // block rows (row n = rhs)
-  for (int k = -1; k + 1 < nb; k++)         // launch k finishes panel k+1
-    hipLaunchKernelGGL(chol_step_kernel, dim3(nrb - k - 1, k < 0 ? 1 : nb - k - 1), dim3(512), 0, s, sys, n, ld, k,
-                       fail_flag);
+  for (int k = -1; k + 1 < nb; k++)         // launch k finishes panel k+1; launch -1 also damps
+    hipLaunchKernelGGL(chol_step_kernel, dim3(nrb - k - 1, k < 0 ? 2 : nb - k - 1), dim3(512), 0, s, sys, n,
+                       ld, k, fail_flag, lm, ep);
 }
 
 void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, int* err,
