@@ -1,7 +1,7 @@
 import sys, ctypes
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/droid-slam_reserch_amd")
 import numpy as np, torch
-lib = ctypes.CDLL("/root/repo/scratch/libs/lib_stamps.so")
+lib = ctypes.CDLL("/root/repo/tools/libs/lib_stamps.so")
 n = 1530
 rng = np.random.default_rng(0)
 A = rng.normal(size=(n, n + 8)); A = A @ A.T + n * 0.1 * np.eye(n); b = rng.normal(size=n)
