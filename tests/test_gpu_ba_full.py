@@ -1,0 +1,149 @@
+"""Full-size (BASELINE.json configs[2..4]) GPU tests of the HIP bundle adjustment: direct parity
+against the fp64 oracle where the oracle finishes in seconds, plus size-independent properties
+(edge-permutation invariance, duplicated-edge == doubled weight, cost reduction, empty graph).
+Everything goes through droid_backends.ba -> C ABI.  Tolerance 1e-4 (north star)."""
+import numpy as np
+import pytest
+
+from util import ba_args, compare_state, run_hip_ba, to_dev
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from droid_backends import synth
+    return synth
+
+
+@pytest.fixture(scope="module")
+def cfg3(synth):
+    return synth.make_config("cfg3")
+
+
+def _copy(p):
+    import copy
+    return copy.deepcopy(p)
+
+
+def _parity(backends, oracle, p, iterations, tag):
+    torch = _torch()
+    hip = run_hip_ba(backends, p, torch, iterations)
+    ref = oracle.ba(*ba_args(p), iterations, p.lm, p.ep, False)
+    assert hip["status"] & 3 == 0
+    assert hip["M"] == ref["M"]
+    et, er, ed = compare_state(hip, ref, tag)
+    assert et < TOL and er < TOL and ed < TOL, (et, er, ed)
+
+
+def test_cfg3_256kf_2000e_matches_oracle(backends, oracle, cfg3):
+    """The graph the headline metric is quoted on, two Gauss-Newton iterations."""
+    _parity(backends, oracle, _copy(cfg3), 2, "cfg3")
+
+
+def test_cfg4_256kf_8000e_matches_oracle(backends, oracle, synth):
+    """Dense graph: 31 edges per source frame on average exercises the multi-block Schur path."""
+    _parity(backends, oracle, synth.make_config("cfg4"), 1, "cfg4")
+
+
+def test_cfg5_stereo_96x128_matches_oracle(backends, oracle, synth):
+    _parity(backends, oracle, synth.make_config("cfg5"), 1, "cfg5")
+
+
+def test_cfg3_edge_permutation_invariance(backends, cfg3):
+    """The solution does not depend on the order of the edge list (only summation order changes)."""
+    torch = _torch()
+    a = run_hip_ba(backends, _copy(cfg3), torch, 2)
+    q = _copy(cfg3)
+    perm = np.random.default_rng(3).permutation(len(q.ii))
+    q.ii, q.jj, q.targets, q.weights = q.ii[perm], q.jj[perm], q.targets[perm], q.weights[perm]
+    b = run_hip_ba(backends, q, torch, 2)
+    et, er, ed = compare_state(a, b, "perm")
+    assert et < TOL and er < TOL and ed < TOL   # fp32 linearisation noise of this graph is ~2e-5
+
+
+def test_cfg3_duplicated_edges_equal_doubled_weights(backends, cfg3):
+    """Linearity of the normal equations in the weights: listing an edge twice == doubling its weight."""
+    torch = _torch()
+    k = 300
+    a = _copy(cfg3)
+    a.weights[:k] *= 2.0
+    ra = run_hip_ba(backends, a, torch, 2)
+    b = _copy(cfg3)
+    b.ii = np.concatenate([b.ii, b.ii[:k]])
+    b.jj = np.concatenate([b.jj, b.jj[:k]])
+    b.targets = np.concatenate([b.targets, b.targets[:k]])
+    b.weights = np.concatenate([b.weights, b.weights[:k]])
+    rb = run_hip_ba(backends, b, torch, 2)
+    et, er, ed = compare_state(ra, rb, "dup")
+    assert et < TOL and er < TOL and ed < TOL   # fp32 linearisation noise of this graph is ~2e-5
+
+
+def _cost(backends, torch, d):
+    """Weighted reprojection cost of the current device state, evaluated with droid_backends.projmap."""
+    coords, valid = backends.projmap(d["poses"], d["disps"], d["intrinsics"], d["ii"], d["jj"])
+    r = d["targets"].permute(0, 2, 3, 1) - coords[..., :2]
+    w = d["weights"].permute(0, 2, 3, 1)
+    return float((w * r * r * valid).double().sum().item())   # valid: depth > MIN_DEPTH, as in the solver
+
+
+def test_cfg3_iterations_reduce_reprojection_cost(backends, cfg3):
+    torch = _torch()
+    p = _copy(cfg3)
+    d = to_dev(p, torch)
+    costs = [_cost(backends, torch, d)]
+    for _ in range(3):
+        backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["targets"], d["weights"],
+                    d["eta"], d["ii"], d["jj"], p.t0, p.t1, 1, p.lm, p.ep, False)
+        costs.append(_cost(backends, torch, d))
+    print("cost per iteration:", ["%.4e" % c for c in costs])
+    assert costs[1] < 0.5 * costs[0]
+    assert costs[3] <= costs[1]
+
+
+def test_cfg3_k_iterations_equal_k_calls(backends, cfg3):
+    """One call with K iterations == K calls with one iteration (same kernels, same order)."""
+    torch = _torch()
+    a = run_hip_ba(backends, _copy(cfg3), torch, 3)
+    p = _copy(cfg3)
+    d = to_dev(p, torch)
+    for _ in range(3):
+        backends.ba(d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["targets"], d["weights"],
+                    d["eta"], d["ii"], d["jj"], p.t0, p.t1, 1, p.lm, p.ep, False)
+    torch.cuda.synchronize()
+    assert np.abs(a["poses"] - d["poses"].cpu().numpy()).max() < 1e-5
+    assert np.abs(a["disps"] - d["disps"].cpu().numpy()).max() < 1e-4
+
+
+def test_empty_graph_is_a_noop(backends, synth):
+    """E = 0: every frame of the window still owns a depth slot (eta rows = t1 - t0); with no
+    observations and disps == disps_sens... the update is exactly zero."""
+    torch = _torch()
+    p = synth.make_ba_problem(N=5, E=12, H=16, W=24, seed=3)
+    p.ii, p.jj = p.ii[:0], p.jj[:0]
+    p.targets, p.weights = p.targets[:0], p.weights[:0]
+    p.eta = np.ascontiguousarray(p.eta[:p.t1 - p.t0]) if p.eta.shape[0] >= p.t1 - p.t0 else \
+        np.full((p.t1 - p.t0,) + p.disps.shape[1:], 1e-3, np.float32)
+    poses0, disps0 = p.poses.copy(), p.disps.copy()
+    hip = run_hip_ba(backends, p, torch, 2)
+    assert hip["status"] & 3 == 0
+    assert np.abs(hip["poses"] - poses0).max() == 0
+    assert np.abs(hip["disps"] - disps0).max() == 0
+    assert np.abs(hip["dx"]).max() == 0
+
+
+def test_all_weights_zero_leaves_state(backends, synth):
+    torch = _torch()
+    p = synth.make_config("cfg1")
+    p.weights[:] = 0
+    poses0, disps0 = p.poses.copy(), p.disps.copy()
+    hip = run_hip_ba(backends, p, torch, 2)
+    assert np.abs(hip["poses"] - poses0).max() < 1e-7
+    assert np.abs(hip["disps"] - disps0).max() < 1e-7
