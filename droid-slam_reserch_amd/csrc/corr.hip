@@ -13,6 +13,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/droid_backends_hip.h"
 
@@ -574,6 +575,418 @@ __global__ __launch_bounds__(ALT_THREADS, 2) void altcorr_forward_tiled(const fl
   }
 }
 
+// ---- altcorr_forward, fp32 matrix-core path ----------------------------------------------------
+// The per-tap dot products of a block of queries against the fmap2 positions their windows cover
+// are a GEMM: D[query][position] = sum_c f1[query][c] * f2[position][c].  One workgroup = a
+// 16 (x) by 4 (y) tile of query pixels; wave w owns the 4x4 sub-tile x in [4w,4w+4) and multiplies
+// its 16 queries (rows) against the bounding box of THEIR windows (16-position column blocks, at
+// most AM_MAXBLK of them) on v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation.
+//
+// The box of the whole workgroup is staged in LDS in stages of 16 channels by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip), as many stages per batch as fit in the 50 KB
+// buffer (all 8 for the small boxes of the coarse levels).  The LDS image is lane-linear
+// (64 B per position, 16 positions per wave-instruction); bank conflicts are avoided by an XOR
+// swizzle applied on the SOURCE side: 16-byte slot s of position P holds channel chunk
+// s ^ ((P >> 1) & 3), so the operand reads of 8 consecutive positions cover all 32 banks.  K is
+// consumed in a permuted order (k-step e of lane group g = channel 4g+e of the stage), identical
+// for both operands, so that A and B fragments are plain 16-byte pieces of channels-last rows.
+//
+// D leaves the accumulators through LDS as dbuf[query][position] (stores with immediate offsets);
+// the bilinear combine walks output columns so that tap rows are shared between consecutive
+// outputs, is written exactly like the generic kernel (same order of the four weighted taps)
+// and stores 64-byte runs of 16 consecutive query pixels.  Instruction count matters as much as
+// the MFMA time here: each SIMD runs 12 waves of this kernel per launch, so every 1000 VALU
+// instructions per wave cost ~20 us.  Computing a box instead of 64 taps per query costs box/64 redundant
+// flops (2.25x for a smooth flow field) on a pipe that is otherwise idle.  A tile whose boxes do
+// not fit (incoherent coordinates) is evaluated per query.
+#ifdef AM_STAMPS
+// Diagnostic build only: s_memtime stamps per wave of the first 64 workgroups of edge (0,0).
+__device__ unsigned long long g_am_stamps[64 * 4 * 32];
+#define AMSTAMP(slot)                                                                              \
+  do {                                                                                             \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0)           \
+      g_am_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define AMNOTE(slot, v)                                                                            \
+  do {                                                                                             \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0)           \
+      g_am_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (slot)] = (unsigned long long)(v);  \
+  } while (0)
+#else
+#define AMSTAMP(slot) do { } while (0)
+#define AMNOTE(slot, v) do { } while (0)
+#endif
+constexpr int AM_TX = 16, AM_TY = 4;     // query tile of a workgroup
+constexpr int AM_CH = 16;                // channels per stage
+constexpr int AM_MAXSTAGE = 8;           // C <= 128 on this path
+constexpr int AM_MAXBLK = 15;            // 16-position blocks per wave (240 positions >= 15x16)
+// D exchange: r=3 keeps 12 blocks per round (50 KB of LDS, 3 workgroups per CU; a second round serves
+// blocks 13..15 of strongly diverging windows); r=4 windows need 13+ blocks even for a smooth flow
+// field, so that variant exchanges all 15 at once (62 KB, 2 workgroups per CU).
+template <int R> struct AmCfg {
+  static constexpr int XBLK = (R <= 3) ? 12 : AM_MAXBLK;
+  static constexpr int CP = 16 * XBLK + 4;      // pitch (== 4 mod 8: 2-way bank conflicts at worst)
+  static constexpr int LDS_FLOATS = 64 * CP;    // staging ring and exchange share this memory
+  static constexpr int MIN_WG = (R <= 3) ? 3 : 2;
+};
+constexpr int AM_MAXPOS = 640;           // largest workgroup box (positions) staged
+constexpr int AM_MAXSLOT = (AM_MAXPOS + 63) / 64;  // DMA instructions per thread and stage
+
+__device__ __forceinline__ int wave_min16(int v) {
+  v = min(v, __shfl_xor(v, 1)); v = min(v, __shfl_xor(v, 2));
+  v = min(v, __shfl_xor(v, 4)); v = min(v, __shfl_xor(v, 8));
+  return v;
+}
+__device__ __forceinline__ int wave_max16(int v) {
+  v = max(v, __shfl_xor(v, 1)); v = max(v, __shfl_xor(v, 2));
+  v = max(v, __shfl_xor(v, 4)); v = max(v, __shfl_xor(v, 8));
+  return v;
+}
+
+template <int R>
+__global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(const float* __restrict__ fmap1,
+                                                               const float* __restrict__ fmap2,
+                                                               const float* __restrict__ coords,
+                                                               float* __restrict__ corr, int N, int H1,
+                                                               int W1, int H2, int W2, int C) {
+  constexpr int RD = 2 * R + 1, NT = RD + 1;
+  constexpr int AM_XBLK = AmCfg<R>::XBLK, AM_CP = AmCfg<R>::CP, AM_LDS_FLOATS = AmCfg<R>::LDS_FLOATS;
+  static_assert(AM_MAXPOS * AM_CH <= AM_LDS_FLOATS, "one stage of the largest box must fit");
+  __shared__ __attribute__((aligned(16))) float lds[AM_LDS_FLOATS];
+  __shared__ int sbox[4][4];  // per wave: x0, y0, width, height of its (clipped) box
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // keep wave-uniform values in SGPRs
+  const int tiles_x = (W1 + AM_TX - 1) / AM_TX;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int n = blockIdx.y, b = blockIdx.z;
+  const int H1W1 = H1 * W1;
+  const float* cbase = coords + ((size_t)b * N + n) * H1W1 * 2;
+  const float* f2b = fmap2 + (size_t)b * H2 * W2 * C;
+
+  AMSTAMP(0);
+  // --- GEMM role: lane (row = lane & 15, g = lane >> 4); row = query (sy, sx) of the sub-tile
+  const int row = lane & 15, g = lane >> 4;
+  const int gqx = tx * AM_TX + 4 * wave + (row & 3), gqy = ty * AM_TY + (row >> 2);
+  const bool gok = gqx < W1 && gqy < H1;
+  const int gpix = gok ? gqy * W1 + gqx : 0;
+  f4 a_all[AM_MAXSTAGE];  // this lane's A fragments of all stages: channels 16 st + 4g .. +3 of its query
+  {
+    const float* f1p = fmap1 + ((size_t)b * H1W1 + gpix) * C + 4 * g;
+#pragma unroll
+    for (int st = 0; st < AM_MAXSTAGE; st++)
+      a_all[st] = (st * AM_CH < C) ? *reinterpret_cast<const f4*>(f1p + st * AM_CH) : f4{0.f, 0.f, 0.f, 0.f};
+  }
+  const Bilin gbl = bilin_setup(cbase[2 * gpix], cbase[2 * gpix + 1], R);
+  {
+    const bool hit = gok && gbl.x1 + NT > 0 && gbl.x1 < W2 && gbl.y1 + NT > 0 && gbl.y1 < H2;
+    const int big = 0x3fffffff;
+    const int x0 = max(wave_min16(hit ? gbl.x1 : big), 0), y0 = max(wave_min16(hit ? gbl.y1 : big), 0);
+    const int x1 = min(wave_max16(hit ? gbl.x1 + NT : -big), W2), y1 = min(wave_max16(hit ? gbl.y1 + NT : -big), H2);
+    if (lane == 0) {
+      sbox[wave][0] = x0; sbox[wave][1] = y0;
+      sbox[wave][2] = max(x1 - x0, 0); sbox[wave][3] = max(y1 - y0, 0);
+    }
+  }
+  __syncthreads();
+  AMSTAMP(1);
+  int bx0 = 0x3fffffff, by0 = 0x3fffffff, bx1 = -0x3fffffff, by1 = -0x3fffffff;
+  bool fits = true, two_rounds = false;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const int sx_ = __builtin_amdgcn_readfirstlane(sbox[w][0]), sy_ = __builtin_amdgcn_readfirstlane(sbox[w][1]);
+    const int sw_ = __builtin_amdgcn_readfirstlane(sbox[w][2]), sh_ = __builtin_amdgcn_readfirstlane(sbox[w][3]);
+    if (sw_ > 0 && sh_ > 0) {
+      bx0 = min(bx0, sx_); by0 = min(by0, sy_);
+      bx1 = max(bx1, sx_ + sw_); by1 = max(by1, sy_ + sh_);
+      fits = fits && (sw_ * sh_ <= 16 * AM_MAXBLK);
+      two_rounds = two_rounds || (sw_ * sh_ > 16 * AM_XBLK);
+    }
+  }
+  const int BW = max(bx1 - bx0, 0), BH = max(by1 - by0, 0);
+  const int npos = BW * BH;
+  fits = fits && npos <= AM_MAXPOS;
+
+  // --- output role: thread -> query (qx_l, qy_l) of the tile, outputs o = og, og+4, ...
+  const int qx_l = tid & 15, qy_l = (tid >> 4) & 3, og = tid >> 6;
+  const int oqx = tx * AM_TX + qx_l, oqy = ty * AM_TY + qy_l;
+  const bool ook = oqx < W1 && oqy < H1;
+  const int opix = ook ? oqy * W1 + oqx : 0;
+#define AM_OUT_ROLE                                                                                    \
+  const Bilin obl = bilin_setup(cbase[2 * opix], cbase[2 * opix + 1], R);                              \
+  const float wnw = f32_value(obl.dy * obl.dx), wne = f32_value(obl.dy * (1.0f - obl.dx));             \
+  const float wsw = f32_value((1.0f - obl.dy) * obl.dx), wse = f32_value((1.0f - obl.dy) * (1.0f - obl.dx)); \
+  float* out = corr + (((size_t)b * N + n) * RD * RD) * H1W1 + opix;   /* weights: ak:119-122 */
+
+  if (!fits) {  // incoherent tile: per-query direct evaluation
+    if (!ook) return;
+    AM_OUT_ROLE
+    const float* f1 = fmap1 + ((size_t)b * H1W1 + opix) * C;
+    for (int o = og; o < RD * RD; o += 4) {
+      const int ox = o / RD, oy = o % RD;
+      float s4[4];
+      for (int t = 0; t < 4; t++) {
+        const int h2 = obl.y1 + oy + (t >> 1), w2 = obl.x1 + ox + (t & 1);
+        float s = 0.f;
+        if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
+          const float* f2 = f2b + ((size_t)h2 * W2 + w2) * C;
+          for (int c = 0; c < C; c += 4) {
+            const f4 u = *reinterpret_cast<const f4*>(f1 + c), v = *reinterpret_cast<const f4*>(f2 + c);
+            s = fmaf(u[0], v[0], s); s = fmaf(u[1], v[1], s); s = fmaf(u[2], v[2], s); s = fmaf(u[3], v[3], s);
+          }
+        }
+        s4[t] = s;
+      }
+      float acc = s4[0] * wse;
+      acc = acc + s4[1] * wsw;
+      acc = acc + s4[2] * wne;
+      acc = acc + s4[3] * wnw;
+      out[(size_t)o * H1W1] = acc;
+    }
+    return;
+  }
+
+  // --- staging plan: DMA instruction k covers positions 16k .. 16k+15 (lane>>2), 16-byte slot
+  // lane&3 of each; this wave issues k = wave, wave+4, ...; source chunk = slot ^ ((P>>1)&3).
+  // Stages live in a ring of `depth` LDS slots; stage s+depth-1 is requested as soon as stage s-1
+  // has been consumed, so DMA latency overlaps the MFMA phases.  The DMAs are issued from inline
+  // asm and retired with counted s_waitcnt vmcnt + raw s_barrier: hipcc would otherwise drain
+  // every outstanding LDS-DMA (vmcnt(0)) in front of each LDS read and each __syncthreads().
+  const int nk = (npos + 15) >> 4;
+  const int slot_floats = nk * (16 * AM_CH);
+  const int nstage = C / AM_CH;                      // <= AM_MAXSTAGE (checked by the launcher)
+  const int cw = nk > wave ? (nk - wave + 3) >> 2 : 0;  // DMA instructions of this wave per stage
+  int depth = min(nstage, AM_LDS_FLOATS / max(slot_floats, 1));
+  depth = max(1, min(depth, 56 / max((nk + 3) >> 2, 1)));   // vmcnt is a 6-bit counter
+  const float rbw = 1.0f / (float)max(BW, 1);
+  int soff[AM_MAXSLOT];  // float offset into fmap2 (without the channel base)
+#pragma unroll
+  for (int it = 0; it < AM_MAXSLOT; it++) {
+    const int P = min(16 * (wave + 4 * it) + (lane >> 2), max(npos - 1, 0));  // pad lanes re-read the last row
+    const int yy = (int)(((float)P + 0.5f) * rbw), xx = P - yy * BW;  // exact: P < 1024, BW < 1024
+    soff[it] = ((by0 + yy) * W2 + (bx0 + xx)) * C + 4 * ((lane & 3) ^ ((lane >> 3) & 3));
+  }
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds);
+  auto issue_stage = [&](int stage, int slot) {
+    const float* src = f2b + stage * AM_CH;
+    const unsigned dst0 = lds_base + 4u * (unsigned)(slot * slot_floats);
+#pragma unroll
+    for (int it = 0; it < AM_MAXSLOT; it++) {
+      const int k = wave + 4 * it;
+      if (k < nk) {  // wave-uniform
+        const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + 4u * (unsigned)(k * (16 * AM_CH)));
+        const float* gsrc = src + soff[it];
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+      }
+    }
+  };
+#define AM_W(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+  auto wait_younger = [&](int n) {  // returns once at most n of this wave's DMAs are outstanding (rounded down)
+    if (n >= 32) AM_W(32); else if (n >= 24) AM_W(24); else if (n >= 16) AM_W(16); else if (n >= 12) AM_W(12);
+    else if (n >= 8) AM_W(8); else if (n >= 6) AM_W(6); else if (n >= 4) AM_W(4); else if (n >= 3) AM_W(3);
+    else if (n >= 2) AM_W(2); else if (n >= 1) AM_W(1); else AM_W(0);
+  };
+
+  // --- this wave's column blocks: LDS offsets (floats) of the B operand rows
+  const int sx0 = __builtin_amdgcn_readfirstlane(sbox[wave][0]), sy0 = __builtin_amdgcn_readfirstlane(sbox[wave][1]);
+  const int sw = __builtin_amdgcn_readfirstlane(sbox[wave][2]), sh = __builtin_amdgcn_readfirstlane(sbox[wave][3]);
+  const int nposw = sw * sh;
+  const int nblk = (nposw + 15) >> 4;  // wave-uniform
+  int boff[AM_MAXBLK];
+  {
+    const float rsw = 1.0f / (float)max(sw, 1);
+    const int rbase = (sy0 - by0) * BW + (sx0 - bx0);
+#pragma unroll
+    for (int blk = 0; blk < AM_MAXBLK; blk++) {
+      const int pp = 16 * blk + row;
+      const int py = (int)(((float)pp + 0.5f) * rsw), px = pp - py * sw;
+      const int r0 = (pp < nposw) ? rbase + py * BW + px : 0;
+      boff[blk] = r0 * AM_CH + 4 * (g ^ ((r0 >> 1) & 3));
+    }
+  }
+  f4 acc[AM_MAXBLK];
+#pragma unroll
+  for (int blk = 0; blk < AM_MAXBLK; blk++) acc[blk] = f4{0.f, 0.f, 0.f, 0.f};
+
+  // the A operand loads were issued at kernel entry; retire them before the first DMA so that no
+  // compiler-generated vmcnt wait lands inside the pipelined loop
+#pragma unroll
+  for (int st = 0; st < AM_MAXSTAGE; st++) asm volatile("" : "+v"(a_all[st]));
+  AMSTAMP(2);
+  AMNOTE(8, nblk); AMNOTE(9, npos); AMNOTE(10, depth);
+#pragma unroll
+  for (int d = 0; d < AM_MAXSTAGE; d++)
+    if (d < depth) issue_stage(d, d);
+  int cur = 0;        // ring slot of stage st
+  int issued = depth; // stages requested so far
+#pragma unroll
+  for (int st = 0; st < AM_MAXSTAGE; st++) {
+    if (st < nstage) {
+      if (depth == 1 && st >= 1) {  // box too large for two slots: no overlap
+        __builtin_amdgcn_s_barrier();
+        issue_stage(st, 0);
+        issued++;
+      }
+      wait_younger((issued - 1 - st) * cw);
+      __builtin_amdgcn_s_barrier();  // stage st visible to all waves; stage st-1 consumed by all
+      if (st == 0) AMSTAMP(3);
+      AMSTAMP(16 + 2 * st);
+      if (depth > 1 && st >= 1 && issued < nstage) {
+        issue_stage(issued, cur == 0 ? depth - 1 : cur - 1);
+        issued++;
+      }
+      const f4 a = a_all[st];
+      const float* bs = lds + cur * slot_floats;
+#pragma unroll
+      for (int grp = 0; grp < AM_MAXBLK / 3; grp++) {
+        if (3 * grp < nblk) {  // wave-uniform; blocks past nblk multiply row 0 and are never read
+          const f4 b0 = *reinterpret_cast<const f4*>(bs + boff[3 * grp]);
+          const f4 b1 = *reinterpret_cast<const f4*>(bs + boff[3 * grp + 1]);
+          const f4 b2 = *reinterpret_cast<const f4*>(bs + boff[3 * grp + 2]);
+          f4 c0 = acc[3 * grp], c1 = acc[3 * grp + 1], c2 = acc[3 * grp + 2];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b2[e], c2, 0, 0, 0);
+          }
+          acc[3 * grp] = c0; acc[3 * grp + 1] = c1; acc[3 * grp + 2] = c2;
+        }
+      }
+      AMSTAMP(17 + 2 * st);
+      cur = (cur + 1 == depth) ? 0 : cur + 1;
+    }
+  }
+#undef AM_W
+  AMSTAMP(4);
+  __syncthreads();
+  // D exchange: dbuf[tile query][position of its wave's box]; lane holds D[query 4g+reg][16 blk + row].
+  // All offsets past the per-lane base are compile-time constants (ds_write with immediates).
+  float* dbuf = lds;
+  {
+    float* dl = dbuf + (wave * 16 + 4 * g) * AM_CP + row;
+#pragma unroll
+    for (int blk = 0; blk < AM_XBLK; blk++) {
+      if (blk < nblk) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) dl[reg * AM_CP + 16 * blk] = acc[blk][reg];
+      }
+    }
+  }
+  __syncthreads();
+  AMSTAMP(5);
+  // Bilinear combine.  Wave og walks output columns ox = og, og+4, ... of all 64 queries of the
+  // tile: the two tap rows of an output are shared with the next one, so a column costs
+  // (2r+2) paired LDS reads for (2r+1) outputs.  Queries whose window leaves the box (plane
+  // border) take the clamped + masked variant; the choice is wave-uniform.
+  AM_OUT_ROLE
+  const int wq = qx_l >> 2;
+  const int osw = sbox[wq][2], osh = sbox[wq][3];
+  const int rx = obl.x1 - sbox[wq][0], ry = obl.y1 - sbox[wq][1];  // window origin inside the wave's box
+  const float* dq = dbuf + (wq * 16 + qy_l * 4 + (qx_l & 3)) * AM_CP;
+  const bool inside = !ook || (rx >= 0 && ry >= 0 && rx + NT <= osw && ry + NT <= osh);
+  if (AM_XBLK < AM_MAXBLK && two_rounds) {
+    // some wave of this tile has more than AM_XBLK position blocks (strongly diverging windows):
+    // the exchange buffer is used twice and every output sums the taps of both rounds
+    constexpr int NOUT = (RD * RD + 3) / 4;
+    float vacc[NOUT];
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+      if (round == 1) {
+        __syncthreads();  // round 0 fully read
+        float* dl = dbuf + (wave * 16 + 4 * g) * AM_CP + row;
+#pragma unroll
+        for (int blk = AM_XBLK; blk < AM_MAXBLK; blk++) {
+          if (blk < nblk) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) dl[reg * AM_CP + 16 * (blk - AM_XBLK)] = acc[blk][reg];
+          }
+        }
+        __syncthreads();
+      }
+      const int lo = round * 16 * AM_XBLK;
+#pragma unroll
+      for (int m = 0; m < NOUT; m++) {
+        const int o = og + 4 * m;
+        const int ox = o / RD, oy = o % RD;
+        float s4[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int yy = ry + oy + (t >> 1), xx = rx + ox + (t & 1);
+          const int nn = yy * osw + xx - lo;
+          const bool ok = yy >= 0 && yy < osh && xx >= 0 && xx < osw && nn >= 0 && nn < 16 * AM_XBLK;
+          s4[t] = dq[ok ? nn : 0];
+          s4[t] = ok ? s4[t] : 0.f;
+        }
+        float v = s4[0] * wse;
+        v = v + s4[1] * wsw;
+        v = v + s4[2] * wne;
+        v = v + s4[3] * wnw;
+        vacc[m] = (round == 0) ? v : vacc[m] + v;
+      }
+    }
+    if (!ook) return;
+#pragma unroll
+    for (int m = 0; m < NOUT; m++)
+      if (og + 4 * m < RD * RD) out[(size_t)(og + 4 * m) * H1W1] = vacc[m];
+  } else if (__all(inside)) {
+    AMNOTE(11, 1);
+    if (!ook) return;
+    for (int ox = og; ox < RD; ox += 4) {
+      const float* dp = dq + ry * osw + rx + ox;
+      float* op = out + (size_t)ox * RD * H1W1;
+      float t0 = dp[0], t1 = dp[1];
+#pragma unroll
+      for (int oy = 0; oy < RD; oy++) {
+        dp += osw;
+        const float u0 = dp[0], u1 = dp[1];
+        float v = t0 * wse;   // tap (oy  , ox  )
+        v = v + t1 * wsw;     // tap (oy  , ox+1)
+        v = v + u0 * wne;     // tap (oy+1, ox  )
+        v = v + u1 * wnw;     // tap (oy+1, ox+1)
+        op[(size_t)oy * H1W1] = v;
+        t0 = u0; t1 = u1;
+      }
+    }
+  } else {
+    if (!ook) return;
+    const int xmax = max(osw - 1, 0), ymax = max(osh - 1, 0);
+    for (int ox = og; ox < RD; ox += 4) {
+      const int xa = rx + ox, xb = xa + 1;
+      const bool ina = xa >= 0 && xa < osw, inb = xb >= 0 && xb < osw;
+      const int xac = min(max(xa, 0), xmax), xbc = min(max(xb, 0), xmax);
+      float* op = out + (size_t)ox * RD * H1W1;
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; j++) {
+        const int yy = ry + j;
+        const bool iny = yy >= 0 && yy < osh;
+        const float* dp = dq + min(max(yy, 0), ymax) * osw;
+        float u0 = dp[xac], u1 = dp[xbc];
+        u0 = (iny && ina) ? u0 : 0.f;
+        u1 = (iny && inb) ? u1 : 0.f;
+        if (j > 0) {
+          float v = t0 * wse;
+          v = v + t1 * wsw;
+          v = v + u0 * wne;
+          v = v + u1 * wnw;
+          op[(size_t)(j - 1) * H1W1] = v;
+        }
+        t0 = u0; t1 = u1;
+      }
+    }
+  }
+  AMSTAMP(6);
+#undef AM_OUT_ROLE
+}
+
+#ifdef AM_STAMPS
+extern "C" int droid_debug_am_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_am_stamps), sizeof(unsigned long long) * 64 * 4 * 32);
+}
+#endif
+
 template <typename T>
 static int altcorr_forward_t(const void* f1, const void* f2, const float* coords, void* corr, int B,
                              int N, int H1, int W1, int H2, int W2, int C, int r, hipStream_t s) {
@@ -588,6 +1001,17 @@ int launch_altcorr_forward(const void* f1, const void* f2, const float* coords, 
                            int N, int H1, int W1, int H2, int W2, int C, int r, int dtype,
                            hipStream_t s) {
   if (B > 65535 || N > 65535) return DROID_E_ARG;
+  if (dtype == DROID_F32 && (C % AM_CH) == 0 && C <= AM_CH * AM_MAXSTAGE && (r == 3 || r == 4) && (long)H2 * W2 * C < (1l << 30) && !getenv("DROID_ALT_VALU")) {
+    const int tiles = ((W1 + AM_TX - 1) / AM_TX) * ((H1 + AM_TY - 1) / AM_TY);
+    dim3 grid(tiles, N, B), block(256);
+    if (r == 3)
+      hipLaunchKernelGGL((altcorr_forward_mfma<3>), grid, block, 0, s, static_cast<const float*>(f1),
+                         static_cast<const float*>(f2), coords, static_cast<float*>(corr), N, H1, W1, H2, W2, C);
+    else
+      hipLaunchKernelGGL((altcorr_forward_mfma<4>), grid, block, 0, s, static_cast<const float*>(f1),
+                         static_cast<const float*>(f2), coords, static_cast<float*>(corr), N, H1, W1, H2, W2, C);
+    return 0;
+  }
   if (dtype == DROID_F32 && (C % ALT_CH) == 0 && (r == 3 || r == 4)) {
     const int tiles = ((W1 + ALT_TQ - 1) / ALT_TQ) * ((H1 + ALT_TQ - 1) / ALT_TQ);
     dim3 grid(tiles, N, B), block(ALT_THREADS);

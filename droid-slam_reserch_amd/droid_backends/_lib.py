@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdroid_backends_hip.so")
+# DROID_HIP_LIB selects another build of the same library (diagnostic builds, tools/README.md)
+LIB_PATH = os.environ.get("DROID_HIP_LIB") or os.path.join(_HERE, "libdroid_backends_hip.so")
 
 # every symbol include/droid_backends_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
