@@ -13,7 +13,6 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/droid_backends_hip.h"
 
@@ -657,8 +656,20 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(co
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // keep wave-uniform values in SGPRs
   const int tiles_x = (W1 + AM_TX - 1) / AM_TX;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int n = blockIdx.y, b = blockIdx.z;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+  // linear id l runs tile (l % 8) * (total / 8) + l / 8: the tiles of one edge, whose fmap2 boxes
+  // overlap, then share one L2 instead of pulling every fmap2 row into all eight.
+  int tile, n, b;
+  {
+    const unsigned ntile = gridDim.x, total = gridDim.x * gridDim.y * gridDim.z;
+    unsigned v = blockIdx.x + ntile * (blockIdx.y + gridDim.y * blockIdx.z);
+    if ((total & 7u) == 0) v = (v & 7u) * (total >> 3) + (v >> 3);
+    tile = (int)(v % ntile);
+    const unsigned e = v / ntile;
+    n = (int)(e % gridDim.y);
+    b = (int)(e / gridDim.y);
+  }
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int H1W1 = H1 * W1;
   const float* cbase = coords + ((size_t)b * N + n) * H1W1 * 2;
   const float* f2b = fmap2 + (size_t)b * H2 * W2 * C;
@@ -669,14 +680,18 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(co
   const int gqx = tx * AM_TX + 4 * wave + (row & 3), gqy = ty * AM_TY + (row >> 2);
   const bool gok = gqx < W1 && gqy < H1;
   const int gpix = gok ? gqy * W1 + gqx : 0;
+  // coordinates first (the box and the staging plan wait for them), then the A fragments, which
+  // stay in flight until the first MFMA
+  float2 gc = *reinterpret_cast<const float2*>(cbase + 2 * gpix);
   f4 a_all[AM_MAXSTAGE];  // this lane's A fragments of all stages: channels 16 st + 4g .. +3 of its query
   {
     const float* f1p = fmap1 + ((size_t)b * H1W1 + gpix) * C + 4 * g;
 #pragma unroll
     for (int st = 0; st < AM_MAXSTAGE; st++)
-      a_all[st] = (st * AM_CH < C) ? *reinterpret_cast<const f4*>(f1p + st * AM_CH) : f4{0.f, 0.f, 0.f, 0.f};
+      a_all[st] = *reinterpret_cast<const f4*>(f1p + min(st * AM_CH, C - AM_CH));  // stages >= C/16 are never used
   }
-  const Bilin gbl = bilin_setup(cbase[2 * gpix], cbase[2 * gpix + 1], R);
+  asm volatile("" : "+v"(gc.x), "+v"(gc.y));  // one 8-byte load ahead of the A loads (hipcc would sink half of it)
+  const Bilin gbl = bilin_setup(gc.x, gc.y, R);
   {
     const bool hit = gok && gbl.x1 + NT > 0 && gbl.x1 < W2 && gbl.y1 + NT > 0 && gbl.y1 < H2;
     const int big = 0x3fffffff;
@@ -809,15 +824,16 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(co
 #pragma unroll
   for (int blk = 0; blk < AM_MAXBLK; blk++) acc[blk] = f4{0.f, 0.f, 0.f, 0.f};
 
-  // the A operand loads were issued at kernel entry; retire them before the first DMA so that no
-  // compiler-generated vmcnt wait lands inside the pipelined loop
-#pragma unroll
-  for (int st = 0; st < AM_MAXSTAGE; st++) asm volatile("" : "+v"(a_all[st]));
   AMSTAMP(2);
   AMNOTE(8, nblk); AMNOTE(9, npos); AMNOTE(10, depth);
 #pragma unroll
   for (int d = 0; d < AM_MAXSTAGE; d++)
     if (d < depth) issue_stage(d, d);
+  // The A fragment loads were issued at kernel entry.  Retire them here, together with the first
+  // `depth` stages (the compiler's vmcnt(0) for these registers also drains the DMAs it cannot
+  // see), so that no compiler-generated vmcnt wait lands inside the pipelined loop.
+#pragma unroll
+  for (int st = 0; st < AM_MAXSTAGE; st++) asm volatile("" : "+v"(a_all[st]));
   int cur = 0;        // ring slot of stage st
   int issued = depth; // stages requested so far
 #pragma unroll
@@ -1001,7 +1017,7 @@ int launch_altcorr_forward(const void* f1, const void* f2, const float* coords, 
                            int N, int H1, int W1, int H2, int W2, int C, int r, int dtype,
                            hipStream_t s) {
   if (B > 65535 || N > 65535) return DROID_E_ARG;
-  if (dtype == DROID_F32 && (C % AM_CH) == 0 && C <= AM_CH * AM_MAXSTAGE && (r == 3 || r == 4) && (long)H2 * W2 * C < (1l << 30) && !getenv("DROID_ALT_VALU")) {
+  if (dtype == DROID_F32 && (C % AM_CH) == 0 && C <= AM_CH * AM_MAXSTAGE && (r == 3 || r == 4) && (long)H2 * W2 * C < (1l << 30)) {
     const int tiles = ((W1 + AM_TX - 1) / AM_TX) * ((H1 + AM_TY - 1) / AM_TY);
     dim3 grid(tiles, N, B), block(256);
     if (r == 3)

@@ -137,6 +137,30 @@ def test_altcorr_multi_coordinate_sets_and_radius4(backends, oracle):
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-5 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("jitter,C,H,W", [(2.6, 128, 16, 32), (10.0, 64, 12, 16), (1.0, 48, 9, 19), (1.5, 256, 8, 16)])
+def test_altcorr_diverging_windows_and_channel_counts(backends, oracle, jitter, C, H, W):
+    """The matrix-core path sizes its work by the bounding box of the windows of 4x4 query
+    sub-tiles: jitter 2.6 px forces the two-round exchange (> 12 position blocks per wave),
+    10 px the per-query evaluation of incoherent tiles; C=48 runs three 16-channel stages,
+    C=256 is served by the LDS-staged vector kernel.  Ragged H x W leaves partial tiles."""
+    torch = _torch()
+    rng = np.random.default_rng(int(jitter * 10) + C)
+    f1 = rng.normal(0, 1, (2, H, W, C)).astype(np.float32)
+    f2 = rng.normal(0, 1, (2, H, W, C)).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    cx = xx[None] + rng.uniform(-jitter, jitter, (2, H, W))
+    cy = yy[None] + rng.uniform(-jitter, jitter, (2, H, W))
+    coords = np.stack([cx, cy], -1)[:, None].astype(np.float32)
+    coords[0, 0, 0, 0] = [-1e9, 3.0]            # far-away coordinates give empty windows (zeros)
+    coords[1, 0, H - 1, W - 1] = [1e9, -1e9]
+    ref = oracle.altcorr_forward(f1, f2, coords, 3, acc_dtype=np.float64)
+    out, = backends.altcorr_forward(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(),
+                                    torch.from_numpy(coords).cuda(), 3)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 1e-5 * np.abs(ref).max()
+
+
 def test_corr_golden_vectors_on_device(backends):
     """Committed fixtures (tests/golden/corr_golden.npz): device output vs stored expected output."""
     import os
