@@ -196,7 +196,10 @@ def bench_corr(args, rank, world, dev, prob):
     out["altcorr_fp32"] = dict(gpix_per_s=pixa / ms_alt / 1e6, ms=ms_alt, edges=Ba,
                                algorithmic_bytes_per_pix=alt_bytes_per_pix,
                                tflops=pixa * alt_flop_per_pix / ms_alt / 1e9,
-                               frac_of_fp32_vector_peak=pixa * alt_flop_per_pix / ms_alt / 1e9 / 157.3)
+                               frac_of_fp32_peak=pixa * alt_flop_per_pix / ms_alt / 1e9 / 157.3,
+                               hbm_gbs=pixa * alt_bytes_per_pix / ms_alt / 1e6,
+                               frac_of_8TBs=pixa * alt_bytes_per_pix / ms_alt / 1e6 / 8000.0,
+                               kernel="altcorr_forward_mfma<3> (fp32 MFMA; useful flops only, the box GEMM does 2-3x more)")
     return out
 
 

@@ -103,13 +103,16 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(d) to fp64 accuracy: fp32 seed + two Newton steps (quadratic: 6e-8 -> 5e-15 -> 1e-16).
+// 1/sqrt(d) to fp64 accuracy: v_rsq_f64 seed + Newton (the pivot wave is instruction-count bound,
+// so the seed comes from the fp64 unit directly instead of cvt -> v_rsq_f32 -> cvt).
 __device__ __forceinline__ double rsqrt_nr(double d) {
-  double y = (double)__frsqrt_rn((float)d);
+  double y = __builtin_amdgcn_rsq(d);
   double e = fma(-d * y, y, 1.0);
   y = fma(0.5 * y, e, y);
+#ifndef CHOL_ONE_NEWTON
   e = fma(-d * y, y, 1.0);
   y = fma(0.5 * y, e, y);
+#endif
   return y;
 }
 
@@ -139,40 +142,71 @@ __device__ __attribute__((noinline)) void wave_gemm_nt16(double* C, const double
 // scalars travel by v_readlane; applied to the identity rows as well they leave L^-T there, so
 // the inverse comes for free and every triangular solve against this block becomes a GEMM.
 // Outputs: L (lower part, in place) and Wl[j*16 + k] = (L^-1)[j][k].
-__device__ __forceinline__ void wave_potrf16(double* Lb, double* Wl, int* fail, bool report) {
+// The wave runs alone on its SIMD and issues ~one instruction per 4-6 cycles whatever the type, so
+// the instruction COUNT is the cost (measured: 3.1-3.5 cycles per removed instruction).  Hence:
+//   * lane r (0..15) keeps row r of the block AND row r of the identity (32 doubles), so that all
+//     multipliers L[c][j] come from lanes of the same 16-lane row and travel by DPP
+//     row_newbcast inside the FMA itself (v_fmac_f64_dpp: one instruction per updated element
+//     instead of two v_readlane + one FMA through an SGPR pair);
+//   * the pivot is broadcast the same way (v_mov_b64_dpp) and 1/sqrt is seeded by v_rsq_f64;
+//   * no per-pivot positivity test: a pivot <= 0 or NaN turns 1/sqrt into NaN, which reaches the
+//     last pivot through the updates, so ONE test at the end sees any failure;
+//   * unconditional row stores (the strict upper triangle of a diagonal block is never read).
+// DPP reads of a VGPR written by the previous VALU instruction need 2 wait states; inline asm is
+// invisible to hipcc's hazard recogniser, hence the explicit s_nop in front of the first DPP use.
+template <int J, int C>
+__device__ __forceinline__ void fmac_bcast(double& acc, const double& piv, const double& own) {
+  // acc -= piv[lane C of this 16-lane row] * own
+  asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc) : "v"(piv), "v"(own), "n"(C));
+}
+template <int J>
+__device__ __forceinline__ void potrf16_pivot(double (&a)[16], double (&w)[16], double& ylast) {
+  double d;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+               : "=v"(d) : "v"(a[J]), "n"(J));
+  const double y = rsqrt_nr(d);
+  if (J == 15) ylast = y;
+  a[J] *= y;
+  w[J] *= y;
+  asm volatile("s_nop 1" : "+v"(a[J]));  // a[J] is the DPP operand of everything below
+#pragma unroll
+  for (int c = J + 1; c < 16; c++) {
+    // unrolled with compile-time lane numbers
+    switch (c) {
+#define DROID_CASE(CC) case CC: if (CC > J) { fmac_bcast<J, CC>(a[CC], a[J], a[J]); fmac_bcast<J, CC>(w[CC], a[J], w[J]); } break;
+      DROID_CASE(1) DROID_CASE(2) DROID_CASE(3) DROID_CASE(4) DROID_CASE(5) DROID_CASE(6) DROID_CASE(7) DROID_CASE(8)
+      DROID_CASE(9) DROID_CASE(10) DROID_CASE(11) DROID_CASE(12) DROID_CASE(13) DROID_CASE(14) DROID_CASE(15)
+#undef DROID_CASE
+      default: break;
+    }
+  }
+}
+
+__device__ __forceinline__ void wave_potrf16(double* Lb, double* Wl, const double* Idn, int* fail, bool report) {
   const int lane = threadIdx.x & 63, row = lane & 15;
-  const bool ident = (lane & 16) != 0;
   __builtin_amdgcn_s_setprio(3);  // the pivot chain outranks the MFMA waves sharing this SIMD
-  double a[16];
+  double a[16], w[16];
 #pragma unroll
   for (int c = 0; c < 16; c++) {
-    const double v = Lb[row * LDP + c];
-    a[c] = ident ? ((c == row) ? 1.0 : 0.0) : v;
+    a[c] = Lb[row * LDP + c];
+    w[c] = Idn[row * 16 + c];
   }
-  bool bad = false;
+  double ylast = 0.0;
+  potrf16_pivot<0>(a, w, ylast);   potrf16_pivot<1>(a, w, ylast);   potrf16_pivot<2>(a, w, ylast);
+  potrf16_pivot<3>(a, w, ylast);   potrf16_pivot<4>(a, w, ylast);   potrf16_pivot<5>(a, w, ylast);
+  potrf16_pivot<6>(a, w, ylast);   potrf16_pivot<7>(a, w, ylast);   potrf16_pivot<8>(a, w, ylast);
+  potrf16_pivot<9>(a, w, ylast);   potrf16_pivot<10>(a, w, ylast);  potrf16_pivot<11>(a, w, ylast);
+  potrf16_pivot<12>(a, w, ylast);  potrf16_pivot<13>(a, w, ylast);  potrf16_pivot<14>(a, w, ylast);
+  potrf16_pivot<15>(a, w, ylast);
+  if (lane < 16) {  // row of L, and row `row` of L^-T: (L^-1)[j][row] = w[j]
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    double d = readlane_f64(a[j], j);
-    if (!(d > 0.0)) {
-      bad = true;
-      d = 1.0;
-    }
-    const double y = rsqrt_nr(d);
-    a[j] = (lane == j) ? d * y : a[j] * y;
-#pragma unroll
-    for (int c = j + 1; c < 16; c++) {
-      const double s = readlane_f64(a[j], c);
-      a[c] = fma(-a[j], s, a[c]);
+    for (int c = 0; c < 16; c++) {
+      Lb[row * LDP + c] = a[c];
+      Wl[c * 16 + row] = w[c];
     }
   }
-  if (lane < 16) {
-#pragma unroll
-    for (int c = 0; c < 16; c++)
-      if (c <= row) Lb[row * LDP + c] = a[c];
-  } else if (lane < 32) {  // lane 16+k holds row k of L^-T: (L^-1)[j][k] = a[j]
-#pragma unroll
-    for (int j = 0; j < 16; j++) Wl[j * 16 + row] = a[j];
-  }
+  const bool bad = !(ylast > 0.0 && ylast < 1.0e300);  // NaN (non-positive pivot somewhere) or overflow
   if (lane == 0 && bad && report) *fail = 1;
   __builtin_amdgcn_s_setprio(0);
 }
@@ -232,6 +266,7 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
   __shared__ double B1[NB * LDP];   // L[bj,k]
   __shared__ double B2[NB * LDP];   // the diagonal tile D -> L
   __shared__ double Wl[4 * 256];    // inverses of the four 16x16 diagonal blocks
+  __shared__ double Idn[256];       // 16x16 identity: initial rows of the lanes that build L^-T
   const int nrows = n + 1;          // row n = right-hand side
   const int kp = k + 1;             // block column being finished
   const int bi = kp + blockIdx.x, bj = kp + blockIdx.y;
@@ -279,6 +314,7 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
   // rows to solve: the own tile, or for the diagonal workgroup the rows of its block below the
   // diagonal tile (only the rhs row, and only when the last block column is narrower than NB)
   const bool solve_rows = !diag || (wk < NB);
+  if (t < 256) Idn[t] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;  // visible after the barrier below
   STAMP(0);
   // T group: wave 4 shares its SIMD with wave 0 (the pivot chain, fp64 VALU) and therefore does no
   // MFMA work; its row group 0 is split over waves 5,6,7 (column tiles {0,1}, {2}, {3}).
@@ -342,7 +378,7 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
   }
   STAMP(2);
   // block (0,0) lives entirely in wave 0's fragments: factor it right away
-  if (wave == 0) wave_potrf16(&B2[0], &Wl[0], fail, diag);
+  if (wave == 0) wave_potrf16(&B2[0], &Wl[0], Idn, fail, diag);
   STAMP(3);
   __syncthreads();
   // rows 0..15 of B0 were an MFMA operand of waves 5..7 until the barrier above
@@ -383,7 +419,7 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
       const int q = p + 1;
       wave_gemm_nt16<false>(&B2[(16 * q) * LDP + 16 * q], &B2[(16 * q) * LDP + 16 * p],
                             &B2[(16 * q) * LDP + 16 * p], LDP);
-      wave_potrf16(&B2[(16 * q) * LDP + 16 * q], &Wl[256 * q], fail, diag);
+      wave_potrf16(&B2[(16 * q) * LDP + 16 * q], &Wl[256 * q], Idn, fail, diag);
       if (p == 0) STAMP(6);
     } else {  // waves 1..7: the other rank-16 updates, round-robin
       int cnt = 0;
