@@ -246,6 +246,29 @@ __device__ __forceinline__ void frag_load_global(f64x4 (&acc)[4], const double* 
     }
 }
 
+// single-tile variants: one 16x16 accumulator fragment (row group rg, column tile nt)
+__device__ __forceinline__ void strip_update_tile(f64x4& acc, const double* Lr, const double* Lc, int rg, int nt) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const double* Ar = &Lr[(16 * rg + r) * LDP + g];
+  const double* Br = &Lc[(16 * nt + r) * LDP + g];
+#pragma unroll 4
+  for (int kk = 0; kk < NB; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ar[kk], Br[kk], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void frag_load_tile(f64x4& acc, const double* __restrict__ S, int ld, int r0, int q0,
+                                               int rg, int nt, int row_end, int col_end, bool lower) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int li = 16 * rg + g + 4 * i, lj = 16 * nt + r;
+    const int row = r0 + li, col = q0 + lj;
+    double v = 0.0;
+    if (row < row_end && col < col_end && (!lower || lj <= li)) v = S[(size_t)row * ld + col];
+    acc[i] = v;
+  }
+}
+
 // One step of the blocked right-looking factorisation in ONE launch of 512-thread workgroups:
 //   every tile (bi >= bj > k) of the trailing matrix:  A[bi,bj] -= L[bi,k] L[bj,k]^T
 //   tiles of block column k+1 additionally finish panel k+1: they rebuild and factor the updated
@@ -316,48 +339,63 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
   const bool solve_rows = !diag || (wk < NB);
   if (t < 256) Idn[t] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;  // visible after the barrier below
   STAMP(0);
-  // T group: wave 4 shares its SIMD with wave 0 (the pivot chain, fp64 VALU) and therefore does no
-  // MFMA work; its row group 0 is split over waves 5,6,7 (column tiles {0,1}, {2}, {3}).
-  f64x4 accx[4];
-  const int x_nt0 = (wave == 5) ? 0 : (wave == 6 ? 2 : 3);
-  if (grp == 0) {
-    frag_load_global<4>(acc, S, ld, c0, c0, w4, 0, c0 + wk, c0 + wk, true);  // diagonal tile
-    if (k < 0) {  // damping of block 0, applied to every workgroup's private copy
+  // Work split of the rank-64 updates (16x16 tiles (rg, nt); D = diagonal tile, lower part only;
+  // T = the tile to solve): wave 0 takes D(0,0) alone and goes straight into its factorisation,
+  // the other 9 D tiles and the 16 T tiles are spread so that every wave has about 4 tiles
+  // (64 MFMAs) and wave 4, which shares its SIMD with the pivot wave, only one.
+  //   w0: D00 | w1: D10 D11 D20 T00 | w2: D21 D22 D30 T01 | w3: D31 D32 D33 T02 | w4: T03 | w5-7: T1x T2x T3x
+  // tile code: bit 4 = T, bits 3:2 = rg, bits 1:0 = nt
+  int ntile, code[4];
+  switch (wave) {
+    case 0: ntile = 1; code[0] = 0x00; code[1] = code[2] = code[3] = 0; break;
+    case 1: ntile = 4; code[0] = 0x04; code[1] = 0x05; code[2] = 0x08; code[3] = 0x10; break;
+    case 2: ntile = 4; code[0] = 0x09; code[1] = 0x0a; code[2] = 0x0c; code[3] = 0x11; break;
+    case 3: ntile = 4; code[0] = 0x0d; code[1] = 0x0e; code[2] = 0x0f; code[3] = 0x12; break;
+    case 4: ntile = 1; code[0] = 0x13; code[1] = code[2] = code[3] = 0; break;
+    default: ntile = 4; code[0] = 0x10 | ((wave - 4) << 2); code[1] = code[0] + 1; code[2] = code[0] + 2; code[3] = code[0] + 3; break;
+  }
+  f64x4 tacc[4];
 #pragma unroll
-      for (int nn = 0; nn < 4; nn++)
+  for (int i = 0; i < 4; i++) {
+    if (i < ntile) {
+      const int rg = (code[i] >> 2) & 3, nt = code[i] & 3;
+      if (code[i] & 0x10) {
+        frag_load_tile(tacc[i], S, ld, r0, c0, rg, nt, nrows, n, diag);                    // tile to solve
+      } else {
+        frag_load_tile(tacc[i], S, ld, c0, c0, rg, nt, c0 + wk, c0 + wk, true);            // diagonal tile
+        if (k < 0 && rg == nt) {  // damping of block 0, applied to every workgroup's private copy
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (16 * w4 + fg + 4 * i == 16 * nn + fr) acc[nn][i] += ep + lm * acc[nn][i];
+          for (int e = 0; e < 4; e++)
+            if (fg + 4 * e == fr) tacc[i][e] += ep + lm * tacc[i][e];
+        }
+      }
     }
-    if (k >= 0) load_tile64(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
-  } else {
-    if (wave != 4) {
-      frag_load_global<4>(acc, S, ld, r0, c0, w4, 0, nrows, n, diag);       // tile to solve
-      if (wave == 5) frag_load_global<2>(accx, S, ld, r0, c0, 0, 0, nrows, n, diag);
-      else frag_load_global<1>(accx, S, ld, r0, c0, 0, x_nt0, nrows, n, diag);
-    }
-    if (k >= 0) load_tile64(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
+  }
+  if (k >= 0) {
+    if (grp == 0) load_tile64(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
+    else load_tile64(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
   }
   __syncthreads();
   STAMP(1);
-  // The diagonal tile gates the pivot chain, so the D group goes first and has the matrix pipe
-  // to itself; the T group's update then overlaps with wave 0's first 16x16 factorisation.
-  // Fragments go to LDS with the final masking folded in; every wave writes only rows it alone
-  // has been reading (B0) or a buffer nobody reads yet (B2).
-  if (grp == 0) {
-    if (k >= 0) strip_update<4>(acc, B1, B1, w4, 0);
+  if (wave == 0) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-    for (int nn = 0; nn < 4; nn++)
+  for (int i = 0; i < 4; i++) {
+    if (i < ntile) {
+      const int rg = (code[i] >> 2) & 3, nt = code[i] & 3;
+      const bool isT = (code[i] & 0x10) != 0;
+      if (k >= 0) strip_update_tile(tacc[i], isT ? B0 : B1, B1, rg, nt);
+      if (!isT) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {  // diagonal tile: strict upper part 0, identity beyond wk
-        const int li = 16 * w4 + fg + 4 * i, lj = 16 * nn + fr;
-        double val = acc[nn][i];
-        if (lj > li) val = 0.0;
-        else if (li >= wk || lj >= wk) val = (li == lj) ? 1.0 : 0.0;
-        B2[li * LDP + lj] = val;
+        for (int e = 0; e < 4; e++) {  // diagonal tile: strict upper part 0, identity beyond wk
+          const int li = 16 * rg + fg + 4 * e, lj = 16 * nt + fr;
+          double val = tacc[i][e];
+          if (lj > li) val = 0.0;
+          else if (li >= wk || lj >= wk) val = (li == lj) ? 1.0 : 0.0;
+          B2[li * LDP + lj] = val;
+        }
       }
+    }
   }
-  if (k >= 0) __syncthreads();  // D group done with the matrix pipe
   auto store_solve = [&](const f64x4& a, int rg, int nt) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {  // tile to solve; the diagonal workgroup keeps only the rows below the tile
@@ -367,27 +405,15 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
       B0[li * LDP + lj] = val;
     }
   };
-  if (grp == 1 && wave != 4) {
-    if (k >= 0) {
-      strip_update<4>(acc, B0, B1, w4, 0);
-      if (wave == 5) strip_update<2>(accx, B0, B1, 0, 0);
-      else strip_update<1>(accx, B0, B1, 0, x_nt0);
-    }
-#pragma unroll
-    for (int nn = 0; nn < 4; nn++) store_solve(acc[nn], w4, nn);  // rows only this wave has been reading
-  }
   STAMP(2);
-  // block (0,0) lives entirely in wave 0's fragments: factor it right away
+  // block (0,0) was updated and written by wave 0 alone: factor it right away
   if (wave == 0) wave_potrf16(&B2[0], &Wl[0], Idn, fail, diag);
   STAMP(3);
   __syncthreads();
-  // rows 0..15 of B0 were an MFMA operand of waves 5..7 until the barrier above
-  if (wave == 5) {
-    store_solve(accx[0], 0, 0);
-    store_solve(accx[1], 0, 1);
-  } else if (wave == 6 || wave == 7) {
-    store_solve(accx[0], 0, x_nt0);
-  }
+  // B0 was an MFMA operand of the T updates until the barrier above: the results go in now
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (i < ntile && (code[i] & 0x10)) store_solve(tacc[i], (code[i] >> 2) & 3, code[i] & 3);
   __syncthreads();
   STAMP(4);
 
