@@ -252,7 +252,9 @@ __device__ __forceinline__ void strip_update_tile(f64x4& acc, const double* Lr, 
   const int r = lane & 15, g = lane >> 4;
   const double* Ar = &Lr[(16 * rg + r) * LDP + g];
   const double* Br = &Lc[(16 * nt + r) * LDP + g];
-#pragma unroll 4
+  // fully unrolled: all 32 operand reads of the tile are in flight before the first MFMA, so the
+  // LDS latency is paid once per tile and the 16 MFMAs issue back to back
+#pragma unroll
   for (int kk = 0; kk < NB; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ar[kk], Br[kk], acc, 0, 0, 0);
 }
 __device__ __forceinline__ void frag_load_tile(f64x4& acc, const double* __restrict__ S, int ld, int r0, int q0,
@@ -269,6 +271,14 @@ __device__ __forceinline__ void frag_load_tile(f64x4& acc, const double* __restr
   }
 }
 
+// acc (16x16 fragment) -= A(16x16 LDS block) * B(16x16 LDS block)^T, both with row pitch LDP
+__device__ __forceinline__ void block_update16(f64x4& acc, const double* A, const double* B) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 16; kk += 4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[r * LDP + kk + g], B[r * LDP + kk + g], acc, 0, 0, 0);
+}
+
 // One step of the blocked right-looking factorisation in ONE launch of 512-thread workgroups:
 //   every tile (bi >= bj > k) of the trailing matrix:  A[bi,bj] -= L[bi,k] L[bj,k]^T
 //   tiles of block column k+1 additionally finish panel k+1: they rebuild and factor the updated
@@ -276,18 +286,20 @@ __device__ __forceinline__ void frag_load_tile(f64x4& acc, const double* __restr
 //   their own tile against it, so panel k+1 is ready when the launch ends.
 // k = -1 is the initial panel (no update).  Grid: (row blocks, column blocks) from k+1.
 //
-// Panel workgroups are organised around the pivot chain, which is the critical path:
-//   waves 0-3 ("D group") own the diagonal tile, waves 4-7 ("T group") the tile to be solved.
-//   * the D group updates the diagonal tile first; wave 0 then factors its 16x16 block (0,0)
-//     on the VALU while the T group's update of the own tile still runs on the matrix pipe;
+// Panel workgroups are organised around the pivot chain (wave 0), which is the critical path:
+//   * up front only the diagonal tile and column 0 of the tile to solve get the rank-64 update of
+//     the previous panel, spread as 16x16 tiles over the eight waves (wave 0: block (0,0) only,
+//     then straight into its factorisation; wave 4, which shares wave 0's SIMD, one tile);
 //   * per 16-column step p: {16x16 solves as GEMMs with the block inverse: one block per wave},
-//     then wave 0 updates block (p+1,p+1) and goes straight into its factorisation while waves
-//     1-7 apply the remaining rank-16 updates.
+//     then wave 0 updates block (p+1,p+1) and factors it while the other waves apply the
+//     remaining rank-16 updates of the diagonal tile and finish column p+1 of the tile to solve
+//     (its rank-64 update was deferred to this slot, where the matrix pipe is otherwise idle).
 __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, int n, int ld, int k,
                                                         int* __restrict__ fail, double lm, double ep) {
-  __shared__ double B0[NB * LDP];   // L[bi,k], later the tile being solved (T -> X)
+  __shared__ double B0[NB * LDP];   // L[bi,k]
   __shared__ double B1[NB * LDP];   // L[bj,k]
   __shared__ double B2[NB * LDP];   // the diagonal tile D -> L
+  __shared__ double BT[NB * LDP];   // the tile being solved (T -> X)
   __shared__ double Wl[4 * 256];    // inverses of the four 16x16 diagonal blocks
   __shared__ double Idn[256];       // 16x16 identity: initial rows of the lanes that build L^-T
   const int nrows = n + 1;          // row n = right-hand side
@@ -339,28 +351,35 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
   const bool solve_rows = !diag || (wk < NB);
   if (t < 256) Idn[t] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;  // visible after the barrier below
   STAMP(0);
-  // Work split of the rank-64 updates (16x16 tiles (rg, nt); D = diagonal tile, lower part only;
-  // T = the tile to solve): wave 0 takes D(0,0) alone and goes straight into its factorisation,
-  // the other 9 D tiles and the 16 T tiles are spread so that every wave has about 4 tiles
-  // (64 MFMAs) and wave 4, which shares its SIMD with the pivot wave, only one.
-  //   w0: D00 | w1: D10 D11 D20 T00 | w2: D21 D22 D30 T01 | w3: D31 D32 D33 T02 | w4: T03 | w5-7: T1x T2x T3x
+  // 16x16 tiles (rg, nt): D = diagonal tile (lower part), T = the tile to solve.  Only what the
+  // first pivot block and the first solve need is updated up front (all of D, column 0 of T);
+  // columns 1..3 of T stay in registers and are finished one per 16-column step, left-looking,
+  // while the pivot wave is busy with the next 16x16 factorisation:
+  //   up front   w0: D00 | w1: D10 D11 | w2: D20 D21 | w3: D30 D31 | w4: T00 | w5: T10 D22 | w6: T20 D32 | w7: T30 D33
+  //   deferred   T(0,q): wave q (q = 1..3);  T(g,q), g = 1..3: wave 4+g
   // tile code: bit 4 = T, bits 3:2 = rg, bits 1:0 = nt
-  int ntile, code[4];
+  int ntile, code[2];
   switch (wave) {
-    case 0: ntile = 1; code[0] = 0x00; code[1] = code[2] = code[3] = 0; break;
-    case 1: ntile = 4; code[0] = 0x04; code[1] = 0x05; code[2] = 0x08; code[3] = 0x10; break;
-    case 2: ntile = 4; code[0] = 0x09; code[1] = 0x0a; code[2] = 0x0c; code[3] = 0x11; break;
-    case 3: ntile = 4; code[0] = 0x0d; code[1] = 0x0e; code[2] = 0x0f; code[3] = 0x12; break;
-    case 4: ntile = 1; code[0] = 0x13; code[1] = code[2] = code[3] = 0; break;
-    default: ntile = 4; code[0] = 0x10 | ((wave - 4) << 2); code[1] = code[0] + 1; code[2] = code[0] + 2; code[3] = code[0] + 3; break;
+    case 0: ntile = 1; code[0] = 0x00; code[1] = 0; break;
+    case 1: ntile = 2; code[0] = 0x04; code[1] = 0x05; break;
+    case 2: ntile = 2; code[0] = 0x08; code[1] = 0x09; break;
+    case 3: ntile = 2; code[0] = 0x0c; code[1] = 0x0d; break;
+    case 4: ntile = 1; code[0] = 0x10; code[1] = 0; break;
+    case 5: ntile = 2; code[0] = 0x14; code[1] = 0x0a; break;
+    case 6: ntile = 2; code[0] = 0x18; code[1] = 0x0e; break;
+    default: ntile = 2; code[0] = 0x1c; code[1] = 0x0f; break;
   }
-  f64x4 tacc[4];
+  const int dg = (wave >= 5) ? wave - 4 : 0;                       // row group of this wave's deferred tiles
+  const int ndef = !solve_rows ? 0 : (wave >= 5 ? 3 : ((wave >= 1 && wave <= 3) ? 1 : 0));
+  f64x4 tacc[2], dacc[3];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < 3; i++) dacc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
     if (i < ntile) {
       const int rg = (code[i] >> 2) & 3, nt = code[i] & 3;
       if (code[i] & 0x10) {
-        frag_load_tile(tacc[i], S, ld, r0, c0, rg, nt, nrows, n, diag);                    // tile to solve
+        if (solve_rows) frag_load_tile(tacc[i], S, ld, r0, c0, rg, nt, nrows, n, diag);   // tile to solve
       } else {
         frag_load_tile(tacc[i], S, ld, c0, c0, rg, nt, c0 + wk, c0 + wk, true);            // diagonal tile
         if (k < 0 && rg == nt) {  // damping of block 0, applied to every workgroup's private copy
@@ -371,20 +390,37 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+    if (i < ndef) frag_load_tile(dacc[i], S, ld, r0, c0, dg, (wave >= 5) ? i + 1 : wave, nrows, n, diag);
   if (k >= 0) {
     if (grp == 0) load_tile64(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
     else load_tile64(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
   }
   __syncthreads();
   STAMP(1);
+  auto store_solve = [&](const f64x4& a, int rg, int nt) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // tile to solve; the diagonal workgroup keeps only the rows below the tile
+      const int li = 16 * rg + fg + 4 * i, lj = 16 * nt + fr;
+      double val = a[i];
+      if (diag && !(li >= wk && r0 + li < nrows && lj < wk)) val = 0.0;
+      BT[li * LDP + lj] = val;
+    }
+  };
   if (wave == 0) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < 2; i++) {
     if (i < ntile) {
       const int rg = (code[i] >> 2) & 3, nt = code[i] & 3;
       const bool isT = (code[i] & 0x10) != 0;
-      if (k >= 0) strip_update_tile(tacc[i], isT ? B0 : B1, B1, rg, nt);
-      if (!isT) {
+      if (isT) {
+        if (solve_rows) {
+          if (k >= 0) strip_update_tile(tacc[i], B0, B1, rg, nt);
+          store_solve(tacc[i], rg, nt);
+        }
+      } else {
+        if (k >= 0) strip_update_tile(tacc[i], B1, B1, rg, nt);
 #pragma unroll
         for (int e = 0; e < 4; e++) {  // diagonal tile: strict upper part 0, identity beyond wk
           const int li = 16 * rg + fg + 4 * e, lj = 16 * nt + fr;
@@ -396,24 +432,10 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
       }
     }
   }
-  auto store_solve = [&](const f64x4& a, int rg, int nt) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {  // tile to solve; the diagonal workgroup keeps only the rows below the tile
-      const int li = 16 * rg + fg + 4 * i, lj = 16 * nt + fr;
-      double val = a[i];
-      if (diag && !(li >= wk && r0 + li < nrows && lj < wk)) val = 0.0;
-      B0[li * LDP + lj] = val;
-    }
-  };
   STAMP(2);
   // block (0,0) was updated and written by wave 0 alone: factor it right away
   if (wave == 0) wave_potrf16(&B2[0], &Wl[0], Idn, fail, diag);
   STAMP(3);
-  __syncthreads();
-  // B0 was an MFMA operand of the T updates until the barrier above: the results go in now
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-    if (i < ntile && (code[i] & 0x10)) store_solve(tacc[i], (code[i] >> 2) & 3, code[i] & 3);
   __syncthreads();
   STAMP(4);
 
@@ -426,49 +448,44 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
         wave_gemm_nt16<true>(&B2[(16 * q) * LDP + 16 * p], &B2[(16 * q) * LDP + 16 * p], &Wl[256 * p], 16);
       } else if (solve_rows && wave < nd + 4) {
         const int g = wave - nd;
-        wave_gemm_nt16<true>(&B0[(16 * g) * LDP + 16 * p], &B0[(16 * g) * LDP + 16 * p], &Wl[256 * p], 16);
+        wave_gemm_nt16<true>(&BT[(16 * g) * LDP + 16 * p], &BT[(16 * g) * LDP + 16 * p], &Wl[256 * p], 16);
       }
     }
     if (p == 0) STAMP(10);
-#ifdef CHOL_STAMPS
-    if (p == 0 && wave == 0) {  // warm repeat of the same call (result discarded into B1, unused by now)
-      for (int rep = 0; rep < 2; rep++) {
-        wave_gemm_nt16<true>(&B1[0], &B2[(16 * 1) * LDP], &Wl[0], 16);
-        STAMP(11 + rep);
-      }
-    }
-#endif
     __syncthreads();
     if (p == 0) STAMP(5);
     if (p == 3) break;
+    const int q = p + 1;
     if (wave == 0) {  // the pivot chain: next diagonal block, then its factorisation
-      const int q = p + 1;
       wave_gemm_nt16<false>(&B2[(16 * q) * LDP + 16 * q], &B2[(16 * q) * LDP + 16 * p],
                             &B2[(16 * q) * LDP + 16 * p], LDP);
       wave_potrf16(&B2[(16 * q) * LDP + 16 * q], &Wl[256 * q], Idn, fail, diag);
       if (p == 0) STAMP(6);
-    } else {  // waves 1..7: the other rank-16 updates, round-robin
+    } else {
+      // waves 1..4: the other rank-16 updates of the diagonal tile, round-robin
       int cnt = 0;
 #pragma unroll 1
-      for (int r = p + 1; r < 4; r++)
+      for (int r = q; r < 4; r++)
 #pragma unroll 1
-        for (int s2 = p + 1; s2 <= r; s2++) {
-          if (r == p + 1 && s2 == p + 1) continue;  // wave 0's block
-          if ((cnt % 7) + 1 == wave)
+        for (int s2 = q; s2 <= r; s2++) {
+          if (r == q && s2 == q) continue;  // wave 0's block
+          if ((cnt & 3) + 1 == wave)
             wave_gemm_nt16<false>(&B2[(16 * r) * LDP + 16 * s2], &B2[(16 * r) * LDP + 16 * p],
                                   &B2[(16 * s2) * LDP + 16 * p], LDP);
           cnt++;
         }
-      if (solve_rows)
-#pragma unroll 1
-        for (int g = 0; g < 4; g++)
-#pragma unroll 1
-          for (int q = p + 1; q < 4; q++) {
-            if ((cnt % 7) + 1 == wave)
-              wave_gemm_nt16<false>(&B0[(16 * g) * LDP + 16 * q], &B0[(16 * g) * LDP + 16 * p],
-                                    &B2[(16 * q) * LDP + 16 * p], LDP);
-            cnt++;
-          }
+      // column q of the tile to solve, left-looking: the rank-64 update by the previous panel and
+      // the rank-16 updates by the columns solved so far, then into LDS for the next solve
+      const bool mine = (wave >= 5) ? (ndef > 0) : (ndef > 0 && wave == q);
+      if (mine) {
+        f64x4 acc = dacc[0];
+        if (k >= 0) strip_update_tile(acc, B0, B1, dg, q);
+        for (int pp = 0; pp <= p; pp++)
+          block_update16(acc, &BT[(16 * dg) * LDP + 16 * pp], &B2[(16 * q) * LDP + 16 * pp]);
+        store_solve(acc, dg, q);
+        dacc[0] = dacc[1];
+        dacc[1] = dacc[2];
+      }
     }
     __syncthreads();
     if (p == 0) STAMP(7);
@@ -477,7 +494,7 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
   if (grp == 0) {
     if (diag) store_tile64(S, B2, ld, c0, c0, c0, c0 + wk, wk, true);
   } else if (solve_rows) {
-    store_tile64(S, B0, ld, r0, c0, max(r0, c0 + wk), min(r0 + NB, nrows), wk, false);
+    store_tile64(S, BT, ld, r0, c0, max(r0, c0 + wk), min(r0 + NB, nrows), wk, false);
   }
   STAMP(9);
 }
