@@ -462,16 +462,20 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
       wave_potrf16(&B2[(16 * q) * LDP + 16 * q], &Wl[256 * q], Idn, fail, diag);
       if (p == 0) STAMP(6);
     } else {
-      // waves 1..4: the other rank-16 updates of the diagonal tile, round-robin
+      // the other rank-16 updates of the diagonal tile, round-robin over the less loaded waves
       int cnt = 0;
 #pragma unroll 1
       for (int r = q; r < 4; r++)
 #pragma unroll 1
         for (int s2 = q; s2 <= r; s2++) {
           if (r == q && s2 == q) continue;  // wave 0's block
-          if ((cnt & 3) + 1 == wave)
-            wave_gemm_nt16<false>(&B2[(16 * r) * LDP + 16 * s2], &B2[(16 * r) * LDP + 16 * p],
-                                  &B2[(16 * s2) * LDP + 16 * p], LDP);
+          {  // waves 1..4 except wave q, which finishes T(0,q) in this slot
+            const int slot = cnt % 3;
+            const int owner = 1 + slot + ((1 + slot >= q) ? 1 : 0);
+            if (owner == wave)
+              wave_gemm_nt16<false>(&B2[(16 * r) * LDP + 16 * s2], &B2[(16 * r) * LDP + 16 * p],
+                                    &B2[(16 * s2) * LDP + 16 * p], LDP);
+          }
           cnt++;
         }
       // column q of the tile to solve, left-looking: the rank-64 update by the previous panel and
@@ -480,8 +484,9 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
       if (mine) {
         f64x4 acc = dacc[0];
         if (k >= 0) strip_update_tile(acc, B0, B1, dg, q);
-        for (int pp = 0; pp <= p; pp++)
-          block_update16(acc, &BT[(16 * dg) * LDP + 16 * pp], &B2[(16 * q) * LDP + 16 * pp]);
+#pragma unroll
+        for (int pp = 0; pp < 3; pp++)  // unrolled: the operand reads of all blocks are in flight together
+          if (pp <= p) block_update16(acc, &BT[(16 * dg) * LDP + 16 * pp], &B2[(16 * q) * LDP + 16 * pp]);
         store_solve(acc, dg, q);
         dacc[0] = dacc[1];
         dacc[1] = dacc[2];
