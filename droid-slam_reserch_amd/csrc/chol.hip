@@ -602,6 +602,11 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
   int cur = 0;
   if (j < nb - 1 && t >= 64) load_tile64_w123(Tt[0], S, ld, (nb - 1) * NB, c0, n, c0 + wj);
   __syncthreads();
+  double Lcol[NB];  // wave 0: column t of the diagonal tile (rows above the diagonal read 0)
+  if (t < 64) {
+#pragma unroll
+    for (int i = 0; i < NB; i++) Lcol[i] = Ld[i * LDP + t];
+  }
   for (int k = nb - 1; k > j; k--) {
     if (t >= 64) {
       if (k - 1 > j) load_tile64_w123(Tt[cur ^ 1], S, ld, (k - 1) * NB, c0, n, c0 + wj);
@@ -640,14 +645,41 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
     if (dead) return;
   }
   if (t < 64) {
+    // L_jj^T x = z by one wave, lane t = unknown t.  Measured: the plain 64-step lane-broadcast
+    // loop cost 150 cycles per step (an LDS read of L[i][t] inside every dependent step).  Here
+    // column t of L_jj sits in registers (loaded before the first poll), each 16-unknown block is
+    // solved inside its own 16-lane row with DPP broadcasts, and the rows above receive the block
+    // through one 16-term update.
+    double xsol = 0.0;
     const double rinv = 1.0 / Ld[t * LDP + t];
-#pragma unroll
-    for (int i = NB - 1; i >= 0; i--) {
-      const double xi = readlane_f64(z * rinv, i);
-      z = (t == i) ? xi : ((t < i) ? fma(-Ld[i * LDP + t], xi, z) : z);
+    const int rr = t & 15, rowb = t >> 4;
+#define DROID_BS_STEP(B, II)                                                                            \
+    {                                                                                                  \
+      double zr = z * rinv, xi;                                                                        \
+      asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" #II " row_mask:0xf bank_mask:0xf"   \
+                   : "=v"(xi) : "v"(zr));                                                              \
+      z = fma(-Lcol[16 * B + II], xi, z);  /* zero for lanes above the diagonal; lane II itself is done */ \
+      xsol = (rr == II) ? xi : xsol;                                                                   \
     }
-    if (__double_as_longlong(z) == BSP_SENTINEL) z = __longlong_as_double(0x7ff8000000000000LL);
-    if (t < wj) __hip_atomic_store(&x[c0 + t], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#define DROID_BS_BLOCK(B)                                                                               \
+    if (rowb == B) {                                                                                   \
+      DROID_BS_STEP(B, 15) DROID_BS_STEP(B, 14) DROID_BS_STEP(B, 13) DROID_BS_STEP(B, 12)              \
+      DROID_BS_STEP(B, 11) DROID_BS_STEP(B, 10) DROID_BS_STEP(B, 9) DROID_BS_STEP(B, 8)                \
+      DROID_BS_STEP(B, 7) DROID_BS_STEP(B, 6) DROID_BS_STEP(B, 5) DROID_BS_STEP(B, 4)                  \
+      DROID_BS_STEP(B, 3) DROID_BS_STEP(B, 2) DROID_BS_STEP(B, 1) DROID_BS_STEP(B, 0)                  \
+      xk[t] = xsol;                                                                                    \
+    }                                                                                                  \
+    if (B > 0 && rowb < B) {                                                                           \
+      _Pragma("unroll") for (int ii = 0; ii < 16; ii++) z = fma(-Lcol[16 * B + ii], xk[16 * B + ii], z); \
+    }
+    DROID_BS_BLOCK(3)
+    DROID_BS_BLOCK(2)
+    DROID_BS_BLOCK(1)
+    DROID_BS_BLOCK(0)
+#undef DROID_BS_BLOCK
+#undef DROID_BS_STEP
+    if (__double_as_longlong(xsol) == BSP_SENTINEL) xsol = __longlong_as_double(0x7ff8000000000000LL);
+    if (t < wj) __hip_atomic_store(&x[c0 + t], xsol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
