@@ -5,7 +5,7 @@ Sharding: the factor graph is partitioned BY SOURCE FRAME
 contiguous range of frames [f0,f1), the depth maps of those frames and every edge whose source
 `ii` lies in the range.  Per Gauss-Newton iteration each rank linearises its edges and reduces its
 depth frames locally (Hii/Hij/Hjj blocks, -E C^-1 E^T, rhs) into the dense (6P+1)^2 fp64 system,
-ONE all-reduce(sum) combines the systems, every rank then runs the identical Cholesky solve (dx
+ONE all-reduce(sum) of its lower triangle + rhs row (packed) combines the systems, every rank then runs the identical Cholesky solve (dx
 is bit-identical on all ranks), back-substitutes its own depth frames and applies the same pose
 retraction.  No other collective is on the data path; `gather_disps` optionally re-assembles the
 depth maps at the end of a call.
@@ -90,6 +90,22 @@ class HipBackend:
         self.system = self.ws[off:off + nel.value * 8].view(torch.float64)
         self.dx = torch.empty((t1 - t0, 6), dtype=torch.float32, device=p.poses.device)
         self.dz = torch.empty((M, H * W), dtype=torch.float32, device=p.poses.device)
+        self._ridx_key = (t1 - t0, nel.value)
+
+    def reduce_index(self):
+        """Flat indices of the entries of `system` that the solve reads: the lower triangle of the
+        6P x 6P matrix plus the rhs row (include/droid_backends_hip.h: rows of `ld` doubles).  The
+        sharded driver all-reduces only these (half the bytes of the dense buffer)."""
+        P, nel = self._ridx_key
+        cache = getattr(self, "_ridx", None)
+        if cache is None or cache[0] != self._ridx_key or cache[1].device != self.system.device:
+            n = 6 * P
+            ld = nel // (n + 1)
+            r = torch.arange(n + 1, device=self.system.device).view(-1, 1)
+            c = torch.arange(ld, device=self.system.device).view(1, -1)
+            idx = ((c <= r) & (c < n)).flatten().nonzero().squeeze(1)
+            self._ridx = cache = (self._ridx_key, idx)
+        return cache[1]
 
     def build(self, p: BAProblemDev, motion_only):
         E, nbuf, H, W, M, t0, t1 = self._dims
@@ -155,7 +171,14 @@ class ShardedBA:
         for _ in range(int(iterations)):
             system = be.build(p, motion_only)
             if world > 1:
-                dist.all_reduce(system, op=dist.ReduceOp.SUM, group=self.group)
+                ridx = be.reduce_index() if hasattr(be, "reduce_index") else None
+                if ridx is None:
+                    dist.all_reduce(system, op=dist.ReduceOp.SUM, group=self.group)
+                else:  # only what the solve reads: lower triangle + rhs row, packed
+                    flat = system.view(-1)
+                    packed = flat.index_select(0, ridx)
+                    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+                    flat.index_copy_(0, ridx, packed)
             be.solve_update(p, lm, ep, motion_only)
         return be.dx
 

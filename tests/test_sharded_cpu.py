@@ -49,6 +49,29 @@ class OracleBackend:
         return self.dx
 
 
+class PackedOracleBackend(OracleBackend):
+    """Like the HIP backend, only the lower triangle + rhs row of `system` are meaningful after
+    the collective: exposes reduce_index() and rebuilds the symmetric matrix from the lower part."""
+
+    def reduce_index(self):
+        n1, n = self.system.shape
+        r = torch.arange(n1).view(-1, 1)
+        c = torch.arange(n).view(1, -1)
+        return ((c <= r) & (c < n)).flatten().nonzero().squeeze(1)
+
+    def build(self, p, motion_only):
+        system = super().build(p, motion_only)
+        n = system.shape[1]
+        system[:n] += torch.triu(torch.full((n, n), 1e30, dtype=torch.float64), 1)  # poison what must not be read
+        return system
+
+    def solve_update(self, p, lm, ep, motion_only):
+        n = self.system.shape[1]
+        low = torch.tril(self.system[:n])
+        self.system[:n] = low + torch.tril(low, -1).T
+        return super().solve_update(p, lm, ep, motion_only)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -57,7 +80,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir, iterations):
+def _worker(rank, world, port, out_dir, iterations, packed=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "droid-slam_reserch_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -73,7 +96,7 @@ def _worker(rank, world, port, out_dir, iterations):
                                disps_sens=f64(prob.disps_sens), targets=f64(sh["targets"]),
                                weights=f64(sh["weights"]), eta=f64(sh["eta"]),
                                ii=torch.from_numpy(sh["ii"]), jj=torch.from_numpy(sh["jj"]))
-    solver = ba_driver.ShardedBA(backend=OracleBackend())
+    solver = ba_driver.ShardedBA(backend=PackedOracleBackend() if packed else OracleBackend())
     dx = solver.run(p, prob.t0, prob.t1, iterations, prob.lm, prob.ep, own=sh["own"])
     solver.gather_disps(p.disps, ranges)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), poses=p.poses.numpy(), disps=p.disps.numpy(),
@@ -82,12 +105,13 @@ def _worker(rank, world, port, out_dir, iterations):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_ba_equals_single_rank(tmp_path, world, oracle):
+@pytest.mark.parametrize("world,packed", [(2, False), (3, False), (2, True)])
+def test_sharded_ba_equals_single_rank(tmp_path, world, packed, oracle):
+    """packed=True: the collective moves only the lower triangle + rhs row (what HipBackend asks for)."""
     from droid_backends import synth
     iterations = 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), iterations), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), iterations, packed), nprocs=world, join=True)
     prob = synth.make_ba_problem(N=8, E=32, H=12, W=16, seed=0)
     ref = oracle.ba(prob.poses, prob.disps, prob.intrinsics, prob.disps_sens, prob.targets, prob.weights,
                     prob.eta, prob.ii, prob.jj, prob.t0, prob.t1, iterations, prob.lm, prob.ep, False)
