@@ -883,7 +883,7 @@ __global__ __launch_bounds__(64 * SW_NW, MINWG) void ba_schur_wide_kernel(
   const int pixl = tid & (SF_TP - 1), part = wave;
   load_slot_meta(sm, v, poses, jj, f, x_beg, nedges, has_self ? 1 : 0);
 
-  constexpr int PF = 4;  // prefetched edges per thread (this thread's first four)
+  constexpr int PF = (CLS == 2) ? 8 : 4;  // prefetched edges per thread (its first PF)
   float pf_q = 0.f, pf_d = 0.f, pf_wr = 0.f, pf_w[2 * PF];
   auto prefetch = [&](int tile) {
     const int k = tile * SF_TP + pixl;
@@ -1178,12 +1178,13 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
         hipLaunchKernelGGL(ba_schur_fused_kernel<true>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
                            intr, weights, ii, jj, wide);
         if (wide) {  // fewer, larger workgroups (512 threads, all rows of the slot resident in LDS)
-          int nsw = 512 / (v.M > 0 ? v.M : 1);
-          nsw = nsw < 1 ? 1 : (nsw > tiles ? tiles : nsw);
+          // pixel splits: every split costs one fp64 atomic per output entry (measured sweet spots)
+          int nsw = 256 / (v.M > 0 ? v.M : 1);
+          nsw = nsw < 2 ? 2 : (nsw > tiles ? tiles : nsw);
           hipLaunchKernelGGL((ba_schur_wide_kernel<SW_MID, 2, 1, 1>), dim3(v.M, nsw, 1), dim3(64 * SW_NW), 0, s, v,
                              poses, disps, intr, weights, ii, jj);
-          int nsb = 512 / (4 * (v.M > 0 ? v.M : 1));  // every split adds one fp64 atomic per output entry
-          nsb = nsb < 1 ? 1 : (nsb > tiles ? tiles : nsb);
+          int nsb = 256 / (4 * (v.M > 0 ? v.M : 1));
+          nsb = nsb < 2 ? 2 : (nsb > tiles ? tiles : nsb);
           hipLaunchKernelGGL((ba_schur_wide_kernel<SW_BIG, 1, 2, 4>), dim3(v.M, nsb, 4), dim3(64 * SW_NW), 0, s, v,
                              poses, disps, intr, weights, ii, jj);
         }
