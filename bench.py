@@ -200,6 +200,13 @@ def bench_corr(args, rank, world, dev, prob):
                                hbm_gbs=pixa * alt_bytes_per_pix / ms_alt / 1e6,
                                frac_of_8TBs=pixa * alt_bytes_per_pix / ms_alt / 1e6 / 8000.0,
                                kernel="altcorr_forward_mfma<3> (fp32 MFMA; useful flops only, the box GEMM does 2-3x more)")
+    # the same work through the fused pyramid entry point (no per-edge feature copies, one launch)
+    cf = c[:Ba].contiguous()
+    ms_pyr = timeit(lambda: db.altcorr_pyramid_forward(pyr, cf, ii[:Ba].contiguous(), jj[:Ba].contiguous(), r), 3)
+    out["altcorr_pyramid_fp32"] = dict(gpix_per_s=pixa / ms_pyr / 1e6, ms=ms_pyr, edges=Ba,
+                                       tflops=pixa * alt_flop_per_pix / ms_pyr / 1e9,
+                                       frac_of_fp32_peak=pixa * alt_flop_per_pix / ms_pyr / 1e9 / 157.3,
+                                       kernel="altcorr_pyramid_mfma<3>: AltCorrBlock.corr_fn in one launch over (pyramid, ii, jj)")
     return out
 
 

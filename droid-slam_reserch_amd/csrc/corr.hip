@@ -642,12 +642,14 @@ __device__ __forceinline__ int wave_max16(int v) {
   return v;
 }
 
+// Body shared by the two entry points below.  f1e / f2b: feature maps of this edge (channels last),
+// cbase: its query coordinates, multiplied by cscale (1, or 2^-level for the pyramid entry point:
+// exact), oute: its (2r+1)^2 output planes, tile: index of the 16x4 query tile.
 template <int R>
-__global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(const float* __restrict__ fmap1,
-                                                               const float* __restrict__ fmap2,
-                                                               const float* __restrict__ coords,
-                                                               float* __restrict__ corr, int N, int H1,
-                                                               int W1, int H2, int W2, int C) {
+__device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e, const float* __restrict__ f2b,
+                                                  const float* __restrict__ cbase, const float cscale,
+                                                  float* __restrict__ oute, const int tile, const int H1,
+                                                  const int W1, const int H2, const int W2, const int C) {
   constexpr int RD = 2 * R + 1, NT = RD + 1;
   constexpr int AM_XBLK = AmCfg<R>::XBLK, AM_CP = AmCfg<R>::CP, AM_LDS_FLOATS = AmCfg<R>::LDS_FLOATS;
   static_assert(AM_MAXPOS * AM_CH <= AM_LDS_FLOATS, "one stage of the largest box must fit");
@@ -656,23 +658,8 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(co
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // keep wave-uniform values in SGPRs
   const int tiles_x = (W1 + AM_TX - 1) / AM_TX;
-  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
-  // linear id l runs tile (l % 8) * (total / 8) + l / 8: the tiles of one edge, whose fmap2 boxes
-  // overlap, then share one L2 instead of pulling every fmap2 row into all eight.
-  int tile, n, b;
-  {
-    const unsigned ntile = gridDim.x, total = gridDim.x * gridDim.y * gridDim.z;
-    unsigned v = blockIdx.x + ntile * (blockIdx.y + gridDim.y * blockIdx.z);
-    if ((total & 7u) == 0) v = (v & 7u) * (total >> 3) + (v >> 3);
-    tile = (int)(v % ntile);
-    const unsigned e = v / ntile;
-    n = (int)(e % gridDim.y);
-    b = (int)(e / gridDim.y);
-  }
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int H1W1 = H1 * W1;
-  const float* cbase = coords + ((size_t)b * N + n) * H1W1 * 2;
-  const float* f2b = fmap2 + (size_t)b * H2 * W2 * C;
 
   AMSTAMP(0);
   // --- GEMM role: lane (row = lane & 15, g = lane >> 4); row = query (sy, sx) of the sub-tile
@@ -685,13 +672,13 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(co
   float2 gc = *reinterpret_cast<const float2*>(cbase + 2 * gpix);
   f4 a_all[AM_MAXSTAGE];  // this lane's A fragments of all stages: channels 16 st + 4g .. +3 of its query
   {
-    const float* f1p = fmap1 + ((size_t)b * H1W1 + gpix) * C + 4 * g;
+    const float* f1p = f1e + (size_t)gpix * C + 4 * g;
 #pragma unroll
     for (int st = 0; st < AM_MAXSTAGE; st++)
       a_all[st] = *reinterpret_cast<const f4*>(f1p + min(st * AM_CH, C - AM_CH));  // stages >= C/16 are never used
   }
   asm volatile("" : "+v"(gc.x), "+v"(gc.y));  // one 8-byte load ahead of the A loads (hipcc would sink half of it)
-  const Bilin gbl = bilin_setup(gc.x, gc.y, R);
+  const Bilin gbl = bilin_setup(gc.x * cscale, gc.y * cscale, R);
   {
     const bool hit = gok && gbl.x1 + NT > 0 && gbl.x1 < W2 && gbl.y1 + NT > 0 && gbl.y1 < H2;
     const int big = 0x3fffffff;
@@ -727,15 +714,15 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(co
   const bool ook = oqx < W1 && oqy < H1;
   const int opix = ook ? oqy * W1 + oqx : 0;
 #define AM_OUT_ROLE                                                                                    \
-  const Bilin obl = bilin_setup(cbase[2 * opix], cbase[2 * opix + 1], R);                              \
+  const Bilin obl = bilin_setup(cbase[2 * opix] * cscale, cbase[2 * opix + 1] * cscale, R);            \
   const float wnw = f32_value(obl.dy * obl.dx), wne = f32_value(obl.dy * (1.0f - obl.dx));             \
   const float wsw = f32_value((1.0f - obl.dy) * obl.dx), wse = f32_value((1.0f - obl.dy) * (1.0f - obl.dx)); \
-  float* out = corr + (((size_t)b * N + n) * RD * RD) * H1W1 + opix;   /* weights: ak:119-122 */
+  float* out = oute + opix;   /* weights: ak:119-122 */
 
   if (!fits) {  // incoherent tile: per-query direct evaluation
     if (!ook) return;
     AM_OUT_ROLE
-    const float* f1 = fmap1 + ((size_t)b * H1W1 + opix) * C;
+    const float* f1 = f1e + (size_t)opix * C;
     for (int o = og; o < RD * RD; o += 4) {
       const int ox = o / RD, oy = o % RD;
       float s4[4];
@@ -997,6 +984,70 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(co
 #undef AM_OUT_ROLE
 }
 
+
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+// linear id l runs virtual id (l % 8) * (total / 8) + l / 8: the tiles of one edge, whose fmap2 boxes
+// overlap, then share one L2 instead of pulling every fmap2 row into all eight.
+__device__ __forceinline__ unsigned am_virtual_id() {
+  const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+  unsigned v = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if ((total & 7u) == 0) v = (v & 7u) * (total >> 3) + (v >> 3);
+  return v;
+}
+
+// altcorr_forward (ak:27-142): grid (tiles, N, B)
+template <int R>
+__global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(const float* __restrict__ fmap1,
+                                                               const float* __restrict__ fmap2,
+                                                               const float* __restrict__ coords,
+                                                               float* __restrict__ corr, int N, int H1,
+                                                               int W1, int H2, int W2, int C) {
+  constexpr int RD = 2 * R + 1;
+  const unsigned v = am_virtual_id();
+  const int tile = (int)(v % gridDim.x);
+  const unsigned e = v / gridDim.x;
+  const int n = (int)(e % gridDim.y), b = (int)(e / gridDim.y);
+  const size_t H1W1 = (size_t)H1 * W1;
+  altcorr_mfma_body<R>(fmap1 + (size_t)b * H1W1 * C, fmap2 + (size_t)b * H2 * W2 * C,
+                       coords + ((size_t)b * N + n) * H1W1 * 2, 1.0f,
+                       corr + (((size_t)b * N + n) * RD * RD) * H1W1, tile, H1, W1, H2, W2, C);
+}
+
+// AltCorrBlock.corr_fn in one launch (modules/corr.py:105-125): edge e correlates frame ii[e] of
+// pyramid level 0 with frame jj[e] of every level, coordinates scaled by 2^-level; no per-edge
+// copies of the feature maps (`pyramid[i][:, jj]`).  grid (tiles, levels, E); output
+// [E, levels*(2r+1)^2, H, W] = torch.cat of the per-level results for one coordinate set.
+struct AltPyramid {
+  const float* level[4];  // [frames, H >> l, W >> l, C] fp32, channels last
+};
+template <int R>
+__global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_pyramid_mfma(AltPyramid pyr,
+                                                               const int64_t* __restrict__ ii,
+                                                               const int64_t* __restrict__ jj,
+                                                               const float* __restrict__ coords,
+                                                               float* __restrict__ corr, int frames, int H1,
+                                                               int W1, int C) {
+  constexpr int RD = 2 * R + 1;
+  const unsigned v = am_virtual_id();
+  const int tile = (int)(v % gridDim.x);
+  const unsigned q = v / gridDim.x;
+  const int lvl = (int)(q % gridDim.y), e = (int)(q / gridDim.y);
+  const int H2 = H1 >> lvl, W2 = W1 >> lvl;
+  const size_t H1W1 = (size_t)H1 * W1;
+  const int64_t fi = ii[e], fj = jj[e];
+  float* oute = corr + ((size_t)e * gridDim.y + lvl) * RD * RD * H1W1;
+  if (fi < 0 || fi >= frames || fj < 0 || fj >= frames || H2 <= 0 || W2 <= 0) {  // contract violation: zeros
+    const int tiles_x = (W1 + AM_TX - 1) / AM_TX;
+    const int qx = (tile % tiles_x) * AM_TX + (threadIdx.x & 15), qy = (tile / tiles_x) * AM_TY + ((threadIdx.x >> 4) & 3);
+    if (qx < W1 && qy < H1)
+      for (int o = threadIdx.x >> 6; o < RD * RD; o += 4) oute[(size_t)o * H1W1 + qy * W1 + qx] = 0.f;
+    return;
+  }
+  const float* lp = lvl == 0 ? pyr.level[0] : (lvl == 1 ? pyr.level[1] : (lvl == 2 ? pyr.level[2] : pyr.level[3]));
+  altcorr_mfma_body<R>(pyr.level[0] + (size_t)fi * H1W1 * C, lp + (size_t)fj * H2 * W2 * C,
+                       coords + (size_t)e * H1W1 * 2, 1.0f / (float)(1 << lvl), oute, tile, H1, W1, H2, W2, C);
+}
+
 #ifdef AM_STAMPS
 extern "C" int droid_debug_am_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_am_stamps), sizeof(unsigned long long) * 64 * 4 * 32);
@@ -1045,6 +1096,25 @@ int launch_altcorr_forward(const void* f1, const void* f2, const float* coords, 
     case DROID_F64: return altcorr_forward_t<double>(f1, f2, coords, corr, B, N, H1, W1, H2, W2, C, r, s);
   }
   return DROID_E_ARG;
+}
+
+// fused AltCorrBlock.corr_fn: see altcorr_pyramid_mfma.  Returns DROID_E_ARG for configurations the
+// matrix-core path does not cover (the caller then runs altcorr_forward per level).
+int launch_altcorr_pyramid_forward(const float* const* levels_dev, const int64_t* ii, const int64_t* jj,
+                                   const float* coords, float* corr, int E, int frames, int H, int W, int C,
+                                   int r, int nlevels, hipStream_t s) {
+  if (nlevels < 1 || nlevels > 4 || (r != 3 && r != 4) || (C % AM_CH) != 0 || C > AM_CH * AM_MAXSTAGE) return DROID_E_ARG;
+  if ((H >> (nlevels - 1)) < 1 || (W >> (nlevels - 1)) < 1 || (long)H * W * C >= (1l << 30)) return DROID_E_ARG;
+  if ((long)E * nlevels > 65535) return DROID_E_ARG;
+  AltPyramid pyr;
+  for (int l = 0; l < 4; l++) pyr.level[l] = levels_dev[l < nlevels ? l : nlevels - 1];
+  const int tiles = ((W + AM_TX - 1) / AM_TX) * ((H + AM_TY - 1) / AM_TY);
+  dim3 grid(tiles, nlevels, E), block(256);
+  if (r == 3)
+    hipLaunchKernelGGL((altcorr_pyramid_mfma<3>), grid, block, 0, s, pyr, ii, jj, coords, corr, frames, H, W, C);
+  else
+    hipLaunchKernelGGL((altcorr_pyramid_mfma<4>), grid, block, 0, s, pyr, ii, jj, coords, corr, frames, H, W, C);
+  return 0;
 }
 
 // ---- altcorr_backward (ak:152-286), fp32, atomics into pre-zeroed gradients ----------------

@@ -9,6 +9,7 @@ PyTorch is plumbing only (device memory, streams); all arithmetic is in the HIP 
 """
 from __future__ import annotations
 
+import ctypes
 import os as _os
 
 import torch
@@ -17,7 +18,8 @@ from . import _lib
 from ._lib import DroidBackendError  # noqa: F401
 
 __all__ = ["ba", "frame_distance", "projmap", "depth_filter", "iproj", "altcorr_forward",
-           "altcorr_backward", "corr_index_forward", "corr_index_backward"]
+           "altcorr_backward", "corr_index_forward", "corr_index_backward",
+           "altcorr_pyramid_forward"]  # the last one is an addition
 
 _DT = {torch.float16: _lib.DROID_F16, torch.float32: _lib.DROID_F32, torch.float64: _lib.DROID_F64}
 _workspaces = {}
@@ -236,6 +238,43 @@ def altcorr_forward(fmap1, fmap2, coords, radius):
     _lib.check(lib.droid_altcorr_forward(fmap1.data_ptr(), fmap2.data_ptr(), coords.data_ptr(), corr.data_ptr(),
                                          B, N, H1, W1, H2, W2, C, r, _corr_dtype(fmap1, "fmap1"), _stream()),
                "altcorr_forward")
+    return [corr]
+
+
+def altcorr_pyramid_forward(pyramid, coords, ii, jj, radius):
+    """AltCorrBlock.corr_fn (droid_slam/modules/corr.py:105-125) in one launch, without the per-edge
+    copies `pyramid[i][:, jj]`: pyramid = AltCorrBlock.pyramid (list of [1, frames, H>>l, W>>l, C]
+    or [frames, ...] float32 tensors), coords [E, H, W, 2] (or [1, E, H, W, 2]) float32 at level-0
+    scale, ii / jj [E] int64.  Returns [corr] with corr [E, levels*(2r+1)^2, H, W] =
+    torch.cat([altcorr_forward(pyramid[0][ii], pyramid[l][jj], coords / 2**l, r) for l], dim=1).
+    Not one of the reference's nine operators."""
+    lib = _lib.load()
+    levels = [p[0] if p.dim() == 5 else p for p in pyramid]
+    if coords.dim() == 5:
+        coords = coords[0]
+    for i, p in enumerate(levels):
+        _check_input(p, f"pyramid[{i}]")
+        if p.dtype != torch.float32:
+            raise RuntimeError("altcorr_pyramid_forward: pyramid must be float32")
+    _check_input(coords, "coords")
+    _check_input(ii, "ii")
+    _check_input(jj, "jj")
+    if coords.dtype != torch.float32 or ii.dtype != torch.int64 or jj.dtype != torch.int64:
+        raise RuntimeError("altcorr_pyramid_forward: coords must be float32 and ii/jj int64")
+    frames, H, W, C = levels[0].shape
+    for l, p in enumerate(levels):
+        if tuple(p.shape) != (frames, H >> l, W >> l, C):
+            raise RuntimeError(f"altcorr_pyramid_forward: pyramid[{l}] must be [{frames},{H >> l},{W >> l},{C}]")
+    E = int(ii.shape[0])
+    if tuple(coords.shape) != (E, H, W, 2) or int(jj.shape[0]) != E:
+        raise RuntimeError("altcorr_pyramid_forward: coords must be [E,H,W,2] and ii, jj [E]")
+    r = int(radius)
+    rd = 2 * r + 1
+    corr = torch.empty((E, len(levels) * rd * rd, H, W), dtype=torch.float32, device=coords.device)
+    ptrs = (ctypes.c_void_p * len(levels))(*[p.data_ptr() for p in levels])
+    _lib.check(lib.droid_altcorr_pyramid_forward(ptrs, ii.data_ptr(), jj.data_ptr(), coords.data_ptr(),
+                                                 corr.data_ptr(), E, int(frames), int(H), int(W), int(C), r,
+                                                 len(levels), _stream()), "altcorr_pyramid_forward")
     return [corr]
 
 

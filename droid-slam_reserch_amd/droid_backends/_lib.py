@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("DROID_HIP_LIB") or os.path.join(_HERE, "libdroid_back
 SYMBOLS = [
     "droid_abi_version", "droid_last_error",
     "droid_corr_index_forward", "droid_corr_index_backward",
-    "droid_altcorr_forward", "droid_altcorr_backward",
+    "droid_altcorr_forward", "droid_altcorr_backward", "droid_altcorr_pyramid_forward",
     "droid_ba_workspace_bytes", "droid_ba", "droid_ba_prepare", "droid_ba_build",
     "droid_ba_solve_update", "droid_ba_profile_iteration", "droid_ba_system", "droid_ba_status", "droid_chol_solve",
     "droid_frame_distance", "droid_projmap", "droid_iproj", "droid_depth_filter",
@@ -52,6 +52,7 @@ def load() -> ctypes.CDLL:
     lib.droid_corr_index_backward.argtypes = [vp, vp, vp] + [c_int] * 7 + [vp]
     lib.droid_altcorr_forward.argtypes = [vp, vp, vp, vp] + [c_int] * 9 + [vp]
     lib.droid_altcorr_backward.argtypes = [vp] * 6 + [c_int] * 8 + [vp]
+    lib.droid_altcorr_pyramid_forward.argtypes = [ctypes.POINTER(vp), vp, vp, vp, vp] + [c_int] * 7 + [vp]
     lib.droid_ba_workspace_bytes.argtypes = [c_int] * 7
     lib.droid_ba_workspace_bytes.restype = sz
     lib.droid_ba.argtypes = [vp] * 9 + [c_int] * 8 + [c_float, c_float, c_int, vp, vp, vp, sz, vp]

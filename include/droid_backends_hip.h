@@ -62,6 +62,20 @@ int droid_altcorr_forward(const void *fmap1, const void *fmap2, const float *coo
                           int B, int N, int H1, int W1, int H2, int W2, int C, int radius,
                           int dtype, void *stream);
 
+/* AltCorrBlock.corr_fn fused over the pyramid levels (droid_slam/modules/corr.py:105-125; SURVEY.md
+ * section 8f row 2): for edge e, level l: altcorr_forward(pyramid[0][ii[e]], pyramid[l][jj[e]],
+ * coords[e] / 2^l, r), all levels in one launch and without the per-edge feature-map copies
+ * (`pyramid[i][:, jj]`) the Python code makes.
+ * pyramid: HOST array of `levels` device pointers, level l = [frames, H>>l, W>>l, C] f32 channels
+ * last (AltCorrBlock.pyramid[l] with its leading batch dimension of 1 dropped);
+ * ii, jj [E] int64 ; coords [E,H,W,2] f32 (one coordinate set) ;
+ * corr [E, levels*(2r+1)^2, H, W] f32 = torch.cat of the per-level results (written completely).
+ * fp32, C % 16 == 0, C <= 128, r in {3,4}, levels <= 4; anything else returns DROID_E_ARG and the
+ * caller keeps using droid_altcorr_forward per level.  An edge index outside [0,frames) gives zeros. */
+int droid_altcorr_pyramid_forward(const float *const *pyramid, const int64_t *ii, const int64_t *jj,
+                                  const float *coords, float *corr, int E, int frames, int H, int W,
+                                  int C, int radius, int levels, void *stream);
+
 /* altcorr_backward (droid.cpp:205-217 -> altcorr_kernel.cu:322-355), fp32 only like the reference.
  * fmap1_grad/fmap2_grad must be zero-filled by the caller (atomic accumulation);
  * coords_grad is not written (the reference returns zeros). */

@@ -161,6 +161,41 @@ def test_altcorr_diverging_windows_and_channel_counts(backends, oracle, jitter, 
     assert np.abs(got - ref).max() < 1e-5 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("r", [3, 4])
+def test_altcorr_pyramid_forward_equals_per_level_calls(backends, oracle, r):
+    """Fused AltCorrBlock.corr_fn (modules/corr.py:105-125): one launch over (pyramid, ii, jj) must
+    equal torch.cat of altcorr_forward on the gathered per-edge maps (bit for bit: same kernel body,
+    coordinates scaled by exact powers of two), and the oracle within 1e-5."""
+    import torch.nn.functional as F
+    torch = _torch()
+    rng = np.random.default_rng(40 + r)
+    frames, C, H, W, E = 5, 64, 16, 32, 7
+    fm = torch.from_numpy((rng.normal(0, 1, (frames, C, H, W)) / 4).astype(np.float32)).cuda()
+    pyramid, x = [], fm
+    for _ in range(4):
+        pyramid.append(x.permute(0, 2, 3, 1).contiguous()[None])  # [1, frames, h, w, C] like AltCorrBlock.pyramid
+        x = F.avg_pool2d(x, 2, stride=2)
+    ii = torch.from_numpy(rng.integers(0, frames, E)).cuda()
+    jj = torch.from_numpy(rng.integers(0, frames, E)).cuda()
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    c = np.stack([xx[None] + rng.uniform(-4, 4, (E, 1, 1)) + rng.uniform(-1.2, 1.2, (E, H, W)),
+                  yy[None] + rng.uniform(-4, 4, (E, 1, 1)) + rng.uniform(-1.2, 1.2, (E, H, W))], -1).astype(np.float32)
+    coords = torch.from_numpy(c).cuda()
+    fused, = backends.altcorr_pyramid_forward(pyramid, coords, ii, jj, r)
+    parts = []
+    for l in range(4):
+        f1 = pyramid[0][0][ii].contiguous()
+        f2 = pyramid[l][0][jj].contiguous()
+        cl = (coords / 2 ** l)[:, None].contiguous()
+        out, = backends.altcorr_forward(f1, f2, cl, r)
+        parts.append(out[:, 0])
+        ref = oracle.altcorr_forward(f1.cpu().numpy(), f2.cpu().numpy(), cl.cpu().numpy(), r, acc_dtype=np.float64)
+        assert np.abs(out.cpu().numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+    per_level = torch.cat(parts, dim=1)
+    assert fused.shape == per_level.shape == (E, 4 * (2 * r + 1) ** 2, H, W)
+    assert torch.equal(fused, per_level)
+
+
 def test_corr_golden_vectors_on_device(backends):
     """Committed fixtures (tests/golden/corr_golden.npz): device output vs stored expected output."""
     import os
