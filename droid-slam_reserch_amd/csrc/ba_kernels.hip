@@ -544,7 +544,7 @@ __device__ unsigned long long g_schur_stamps[8 * 16];
 #endif
 
 constexpr int SF_TP = 64;             // pixels per LDS tile; 4 threads per pixel split the edges
-constexpr int SF_PITCH = SF_TP + 2;   // conflict-free b32 MFMA operand reads
+constexpr int SF_PITCH = SF_TP + 4;   // 16-byte aligned rows, conflict-free 16-byte MFMA operand reads
 constexpr int SF_RB = 96;             // rows per block (16 entries)
 constexpr int SF_MAXT = 11;           // max 16x16 output tiles per wave: ceil(7*6/4)
 
@@ -585,8 +585,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
     BaView v, const float* __restrict__ poses, const float* __restrict__ disps,
     const float* __restrict__ intrinsics, const float* __restrict__ weights,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int wide) {
-  __shared__ float EA[(SF_RB + 16) * SF_PITCH];  // row block A (+ the w row, padded to a full tile)
-  __shared__ float EB[MULTI ? SF_RB * SF_PITCH : 4];  // row block B (only for off-diagonal block pairs)
+  __shared__ __attribute__((aligned(16))) float EA[(SF_RB + 16) * SF_PITCH];  // row block A (+ the w row, padded to a full tile)
+  __shared__ __attribute__((aligned(16))) float EB[MULTI ? SF_RB * SF_PITCH : 4];  // row block B (only for off-diagonal block pairs)
   __shared__ float SP[4 * 6 * SF_TP];            // partial self rows of the four edge subsets
   __shared__ SlotMeta sm;
   if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
@@ -764,11 +764,18 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
               ta = ti / tb_n;
               tb = ti % tb_n;
             }
-            const float* pa = &EA[(16 * ta + r) * SF_PITCH + g];
-            const float* pb = &Bs[(16 * tb + r) * SF_PITCH + g];
+            // 16-byte operand reads; K runs in a permuted order (k-step (s,e) of lane group g = pixel
+            // 16s+4g+e), identical for both operands
+            const float* pa = &EA[(16 * ta + r) * SF_PITCH + 4 * g];
+            const float* pb = &Bs[(16 * tb + r) * SF_PITCH + 4 * g];
             f32x4 c = acc[t];
-#pragma unroll 8
-            for (int kk = 0; kk < SF_TP; kk += 4) c = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk], pb[kk], c, 0, 0, 0);
+#pragma unroll
+            for (int s4 = 0; s4 < SF_TP; s4 += 16) {
+              const f32x4 av = *reinterpret_cast<const f32x4*>(pa + s4);
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + s4);
+#pragma unroll
+              for (int e = 0; e < 4; e++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], c, 0, 0, 0);
+            }
             acc[t] = c;
           }
         }

@@ -1,6 +1,6 @@
 import sys, ctypes, shutil
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/droid-slam_reserch_amd")
-shutil.copy("/root/repo/tools/libs/lib_sstamps.so", "/root/repo/droid-slam_reserch_amd/droid_backends/libdroid_backends_hip.so")
+import os; os.environ["DROID_HIP_LIB"] = "/root/repo/tools/libs/lib_sstamps.so"
 import numpy as np, torch
 import droid_backends as db
 from droid_backends import synth
