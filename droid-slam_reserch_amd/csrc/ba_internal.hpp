@@ -36,7 +36,10 @@ struct BaView {
   float* Hpart;            // [E][nch][32] per-(edge,chunk) partial Hjj (21) + vj (6)
   float* Q;                // [M][HW] 1/C
   float* w;                // [M][HW]
-  float* Erows;            // [M+E][6][HW]: self rows Ei, then Eij rows
+  float* Erows;            // unused (nullptr): sparse slots recompute their E rows where they are consumed
+  float* Ebuf;             // dense graphs only (`wide`): unscaled E rows [6*(M+E)][HW], row 6*(entry)+n, written by
+                           // the linearisation and consumed by the SYRK-only Schur kernel
+  int wide;                // host decision: mean out-degree >= 12 (dense global BA, edge-sharded ranks)
   double* sys;             // [n+1][ld] reduced camera system, lower triangle, row n = rhs
   double* xsol;            // [ld] solve scratch / solution
   float* dx;               // [P][6]
@@ -75,7 +78,10 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.Hpart = static_cast<float*>(take(sizeof(float) * ((size_t)E * v.nch * 32 + 32)));
   v.Q = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
   v.w = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
-  v.Erows = nullptr;  // E rows are recomputed where they are consumed, never stored
+  v.Erows = nullptr;  // E rows are recomputed where they are consumed, never stored ...
+  v.wide = (M > 0 && (long)E >= 12l * M && (v.HW % 32) == 0) ? 1 : 0;
+  v.Ebuf = nullptr;   // ... except for dense graphs, where the recomputation would be repeated per output share
+  if (v.wide) v.Ebuf = static_cast<float*>(take(sizeof(float) * (6 * ((size_t)M + E) * v.HW + 64)));
   v.sys = static_cast<double*>(take(sizeof(double) * ((size_t)(v.n + 1) * v.ld + 8)));
   v.xsol = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld + 1)));
   v.dx = static_cast<float*>(take(sizeof(float) * ((size_t)v.n + 8)));

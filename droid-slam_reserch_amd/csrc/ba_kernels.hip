@@ -110,6 +110,23 @@ struct SlotMeta {
   float T[SLOT_MAXE][8];  // relative pose t[3], q[4]
 };
 
+constexpr int SF_TP = 64;             // pixels per LDS tile; 4 threads per pixel split the edges
+constexpr int SF_RB = 96;             // rows per block (16 entries)
+// Dense slots (more than 16 entries) are served by the wide kernels further down.
+constexpr int SW_PITCH = SF_TP + 4;
+constexpr int SW_NW = 8;      // waves per workgroup = threads per pixel in the staging phase
+constexpr int SW_MID = 208;   // rows (incl. the w row) served by the two-per-CU variant
+constexpr int SW_BIG = 512;   // rows served by the one-per-CU variant (85 entries)
+
+// which kernel serves a slot: 0 = single 96-row block, 1/2 = wide kernels, 3 = block pairs.
+// `wide` is a host-side decision (mean out-degree of the graph): sparse graphs skip the two wide
+// launches altogether and leave their few dense slots to the block-pair kernel
+__device__ __forceinline__ int schur_class(int rows, int nedges, int wide) {
+  if (rows <= SF_RB) return 0;
+  if (!wide || nedges > SLOT_MAXE || rows > SW_BIG) return 3;
+  return rows <= SW_MID ? 1 : 2;
+}
+
 // Loads edges [x0, x0+cnt) of slot m (cnt <= SLOT_MAXE) by the first cnt threads of the workgroup.
 // ent_base = entry index of the first window edge of this chunk.  Ends with a barrier.
 __device__ __forceinline__ void load_slot_meta(SlotMeta& sm, const BaView& v, const float* __restrict__ poses,
@@ -294,7 +311,9 @@ __global__ __launch_bounds__(1024) void ba_prep_kernel(BaView v, const int64_t* 
 //                + accum of C, w, Ei :1397-1402 fused).
 // DEPTH = false: motion-only (:1385-1392): blockIdx.x = edge, only the Hjj/vj partials.
 // ------------------------------------------------------------------------------------------
-template <bool DEPTH>
+// EROWS (dense graphs): slots that the SYRK-only Schur kernel will serve also get their UNSCALED E rows
+// written to v.Ebuf (row 6*entry + n; the self row Ei = -sum_e Adj^T Eij is accumulated per pixel).
+template <bool DEPTH, bool EROWS>
 __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
     BaView v, const float* __restrict__ poses, const float* __restrict__ disps,
     const float* __restrict__ intrinsics, const float* __restrict__ disps_sens,
@@ -319,6 +338,22 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
     if (i0 < 0 || i0 >= v.nbuf || j0 < 0 || j0 >= v.nbuf) return;
   }
   const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+
+  // E-row emission for this slot?
+  bool emit = false, has_self = false;
+  int e0 = 0;
+  if (DEPTH && EROWS) {
+    e0 = v.ent_ptr[m];
+    const int nent = v.ent_ptr[m + 1] - e0;
+    const int cls = schur_class(6 * nent + 1, xe - xb, 1);
+    emit = (cls == 1 || cls == 2);
+    has_self = nent > 0 && (v.ent_row[e0] < v.M);
+  }
+  float selfacc[LIN_PPT][6];
+#pragma unroll
+  for (int p = 0; p < LIN_PPT; p++)
+#pragma unroll
+    for (int n = 0; n < 6; n++) selfacc[p][n] = 0.f;
 
   int pix[LIN_PPT];
   float disp[LIN_PPT], Cacc[LIN_PPT], wacc[LIN_PPT];
@@ -350,7 +385,7 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
   for (int x = xb; x < xe; x++) {
     if (DEPTH && ((x - xb) % SLOT_MAXE) == 0) {  // (re)load the metadata chunk of this slot
       if (x > xb) __syncthreads();
-      load_slot_meta(sm, v, poses, jj, f, x, min(SLOT_MAXE, xe - x), 0);
+      load_slot_meta(sm, v, poses, jj, f, x, min(SLOT_MAXE, xe - x), (EROWS && has_self) ? 1 : 0);
     }
     const int xl = DEPTH ? (x - xb) % SLOT_MAXE : 0;
     const int e = DEPTH ? sm.e[xl] : x;
@@ -410,6 +445,23 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
           }
           acc[21 + a] += wa_u * L.ru + wa_v * L.rv;
         }
+        if (DEPTH && EROWS && emit) {  // E row of this (edge, pixel), dk:341, :374 (weights after the stereo rule)
+          const float su = wu * L.Jzu, sv = wv * L.Jzv;
+          float eij[6];
+#pragma unroll
+          for (int n = 0; n < 6; n++) eij[n] = su * L.Ju[n] + sv * L.Jv[n];
+          const int a = sm.ent[xl];
+          if (a >= 0) {
+#pragma unroll
+            for (int n = 0; n < 6; n++) v.Ebuf[(size_t)(6 * (e0 + a) + n) * HW + k] = eij[n];
+          }
+          if (has_self) {
+            float eii[6];
+            adj_se3(T.t, T.q, eij, eii);
+#pragma unroll
+            for (int n = 0; n < 6; n++) selfacc[p][n] -= eii[n];
+          }
+        }
       }
     }
     // workgroup sum of the 27 block entries -> Hpart[e][chunk][0..31]
@@ -438,6 +490,10 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
         const float w = wacc[p] - ms * alpha * (disp[p] - sens);               // dk:1399
         v.Q[o] = 1.0f / C;                                                     // dk:1400
         v.w[o] = w;
+        if (EROWS && emit && has_self) {
+#pragma unroll
+          for (int n = 0; n < 6; n++) v.Ebuf[(size_t)(6 * e0 + n) * HW + k] = selfacc[p][n];
+        }
       }
     }
   }
@@ -543,25 +599,8 @@ __device__ unsigned long long g_schur_stamps[8 * 16];
 #define SSTAMP(i) do { } while (0)
 #endif
 
-constexpr int SF_TP = 64;             // pixels per LDS tile; 4 threads per pixel split the edges
 constexpr int SF_PITCH = SF_TP + 4;   // 16-byte aligned rows, conflict-free 16-byte MFMA operand reads
-constexpr int SF_RB = 96;             // rows per block (16 entries)
 constexpr int SF_MAXT = 11;           // max 16x16 output tiles per wave: ceil(7*6/4)
-
-// Dense slots (more than 16 entries) are served by the wide kernels further down.
-constexpr int SW_PITCH = SF_TP + 4;
-constexpr int SW_NW = 8;      // waves per workgroup = threads per pixel in the staging phase
-constexpr int SW_MID = 208;   // rows (incl. the w row) served by the two-per-CU variant
-constexpr int SW_BIG = 512;   // rows served by the one-per-CU variant (85 entries)
-
-// which kernel serves a slot: 0 = single 96-row block, 1/2 = wide kernels, 3 = block pairs.
-// `wide` is a host-side decision (mean out-degree of the graph): sparse graphs skip the two wide
-// launches altogether and leave their few dense slots to the block-pair kernel
-__device__ __forceinline__ int schur_class(int rows, int nedges, int wide) {
-  if (rows <= SF_RB) return 0;
-  if (!wide || nedges > SLOT_MAXE || rows > SW_BIG) return 3;
-  return rows <= SW_MID ? 1 : 2;
-}
 
 // E row (6 values, already scaled by `scale`) of one (edge, pixel)
 __device__ __forceinline__ void e_row(const Intr& K, const Rel& T, bool stereo, int k, int W, float disp,
@@ -1029,6 +1068,140 @@ __global__ __launch_bounds__(64 * SW_NW, MINWG) void ba_schur_wide_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Dense slots, SYRK only.  With 17..85 entries per slot the accumulators of S = B Q B^T no longer
+// fit one CU, so several workgroups share the output tiles of a (slot, pixel range) and each
+// needs ALL rows of the slot: recomputing the E rows per share (ba_schur_wide_kernel) repeats the
+// whole staging arithmetic 2-4 times and alternates VALU and MFMA phases.  For such graphs the
+// linearisation writes the unscaled E rows once (v.Ebuf) and this kernel only streams them:
+// 32-pixel stages of all rows (+ the w row and the Q row) arrive by LDS-DMA (global_load_lds_dwordx4
+// from inline asm, two buffers, the DMA of stage s+1 in flight while stage s is multiplied), the
+// LDS image is lane-linear (128 B per row) with the XOR swizzle applied on the source side
+// (16-byte slot c of row r holds chunk c ^ (r & 7): 8 consecutive rows cover all banks), K runs
+// in the permuted order (k-step (s,e) of lane group g = pixel 16s+4g+e) and the A operand is
+// scaled by Q on the fly: S_ij = sum_k (B_ik Q_k) B_jk; row R = w gives the reduced rhs E Q w.
+// ------------------------------------------------------------------------------------------
+constexpr int SY_TPX = 32;  // pixels per stage
+
+template <int ROWS, int MINWG, int CLS, int NSHARE>
+__global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
+  constexpr int NW = 8, NRT = ROWS / 16;
+  constexpr int MAXT = ((NRT * (NRT + 1) / 2 + NSHARE - 1) / NSHARE + NW - 1) / NW;
+  constexpr int BUF_FLOATS = (ROWS + 8) * SY_TPX;       // + the Q row, rounded up to a DMA group of 8 rows
+  constexpr int MAXSLOT = ((ROWS + 8) / 8 + NW - 1) / NW;  // DMA instructions per wave and stage
+  __shared__ __attribute__((aligned(16))) float EB[2][BUF_FLOATS];
+  if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
+  const int m = v.order[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int HW = v.HW;
+  const int e0 = v.ent_ptr[m], nent = v.ent_ptr[m + 1] - e0;
+  if (nent == 0) return;
+  const int R = 6 * nent;  // E rows; row R is the w row, row R+1 the Q row
+  const int nedges = v.seg_ptr[m + 1] - v.seg_ptr[m];
+  if (schur_class(R + 1, nedges, 1) != CLS) return;
+  const int stages_total = HW / SY_TPX;  // v.wide guarantees HW % 32 == 0
+  const int spw = (stages_total + gridDim.y - 1) / gridDim.y;
+  const int st_beg = blockIdx.y * spw, st_end = min(stages_total, st_beg + spw);
+  if (st_beg >= st_end) return;
+  const int ntr = (R + 1 + 15) / 16;
+  const int ntiles_all = ntr * (ntr + 1) / 2;
+  const int tshare = (ntiles_all + NSHARE - 1) / NSHARE;
+  const int tile0 = (int)blockIdx.z * tshare;
+  const int ntiles = min(tshare, ntiles_all - tile0);
+  if (ntiles <= 0) return;
+
+  // staging plan: DMA instruction k covers rows 8k..8k+7 (lane >> 3), 16-byte slot lane & 7 of each
+  const int nrows = R + 2;
+  const int ngrp = (nrows + 7) >> 3;
+  const float* src[MAXSLOT];
+#pragma unroll
+  for (int it = 0; it < MAXSLOT; it++) {
+    const int row = min(8 * (wave + NW * it) + (lane >> 3), nrows - 1);  // pad lanes re-read the Q row
+    const float* rp = row < R ? v.Ebuf + (size_t)(6 * e0 + row) * HW
+                              : (row == R ? v.w + (size_t)m * HW : v.Q + (size_t)m * HW);
+    src[it] = rp + 4 * ((lane & 7) ^ (row & 7));
+  }
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) float*)&EB[0][0]);
+  auto issue_stage = [&](int st, int buf) {
+#pragma unroll
+    for (int it = 0; it < MAXSLOT; it++) {
+      const int k = wave + NW * it;
+      if (k < ngrp) {  // wave-uniform
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 4u * (unsigned)(buf * BUF_FLOATS + k * 8 * SY_TPX));
+        const float* gsrc = src[it] + (size_t)st * SY_TPX;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+      }
+    }
+  };
+
+  const int r = lane & 15, g = lane >> 4;
+  f32x4 acc[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int qrow = R + 1;
+  issue_stage(st_beg, 0);
+  for (int st = st_beg; st < st_end; st++) {
+    const int buf = (st - st_beg) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage st has landed
+    __builtin_amdgcn_s_barrier();                     // everybody's has; stage st-1 is consumed
+    if (st + 1 < st_end) issue_stage(st + 1, buf ^ 1);
+    const float* Eb = EB[buf];
+    f32x4 q4[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++)
+      q4[s2] = *reinterpret_cast<const f32x4*>(&Eb[qrow * SY_TPX + 4 * ((4 * s2 + g) ^ (qrow & 7))]);
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+      if (wave + NW * t < ntiles) {
+        int ta, tb;
+        tri_coords(tile0 + wave + NW * t, ta, tb);
+        const int ra = 16 * ta + r, rb = 16 * tb + r;
+        f32x4 c = acc[t];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          f32x4 av = *reinterpret_cast<const f32x4*>(&Eb[ra * SY_TPX + 4 * ((4 * s2 + g) ^ (ra & 7))]);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(&Eb[rb * SY_TPX + 4 * ((4 * s2 + g) ^ (rb & 7))]);
+          av = av * q4[s2];
+#pragma unroll
+          for (int e = 0; e < 4; e++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], c, 0, 0, 0);
+        }
+        acc[t] = c;
+      }
+    }
+  }
+  // ---- fold the accumulators into the dense system (A - S): lower triangle, fp64 atomics
+#pragma unroll
+  for (int t = 0; t < MAXT; t++) {
+    if (wave + NW * t < ntiles) {
+      int ta, tb;
+      tri_coords(tile0 + wave + NW * t, ta, tb);
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        const int li = 16 * ta + 4 * g + x;  // row of the slot (A side)
+        const int lj = 16 * tb + r;          // B side, always an E row
+        if (lj >= R || li > R) continue;
+        const double val = -(double)acc[t][x];
+        const int gj = 6 * v.ent_pose[e0 + lj / 6] + lj % 6;
+        if (li == R) {  // w row: reduced rhs
+          atomicAdd(&v.sys[(size_t)v.n * v.ld + gj], val);
+          continue;
+        }
+        const int gi = 6 * v.ent_pose[e0 + li / 6] + li % 6;
+        if (ta == tb) {  // diagonal tile: both (li,lj) and (lj,li) are computed
+          if (gi >= gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
+        } else {  // the mirror element is not computed: fold it into the lower triangle
+          if (gi > gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
+          else if (gi < gj) atomicAdd(&v.sys[(size_t)gj * v.ld + gi], val);
+          else atomicAdd(&v.sys[(size_t)gi * v.ld + gj], 2.0 * val);
+        }
+      }
+    }
+  }
+}
+
 #ifdef SCHUR_STAMPS
 extern "C" int droid_debug_schur_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_schur_stamps), sizeof(unsigned long long) * 8 * 16);
@@ -1161,10 +1334,14 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
     case 0:
       (void)hipMemsetAsync(v.sys, 0, sizeof(double) * (size_t)(v.n + 1) * v.ld, s);
       if (depth)
-        hipLaunchKernelGGL(ba_lin_kernel<true>, dim3(v.M, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
-                           disps, intr, sens, targets, weights, eta, ii, jj);
+        if (v.wide)
+          hipLaunchKernelGGL((ba_lin_kernel<true, true>), dim3(v.M, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
+                             disps, intr, sens, targets, weights, eta, ii, jj);
+        else
+          hipLaunchKernelGGL((ba_lin_kernel<true, false>), dim3(v.M, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
+                             disps, intr, sens, targets, weights, eta, ii, jj);
       else if (v.E > 0)
-        hipLaunchKernelGGL(ba_lin_kernel<false>, dim3(v.E, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
+        hipLaunchKernelGGL((ba_lin_kernel<false, false>), dim3(v.E, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
                            disps, intr, sens, targets, weights, eta, ii, jj);
       break;
     case 1:
@@ -1179,21 +1356,19 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
         nsplit = nsplit < 1 ? 1 : (nsplit > tiles ? tiles : nsplit);
         // dense graphs (mean out-degree >= 12: global BA of a well connected graph, edge-sharded
         // ranks) send their slots of 17..85 entries to the wide kernels
-        const int wide = (v.E >= 12 * v.M) ? 1 : 0;
+        const int wide = v.wide;
         hipLaunchKernelGGL(ba_schur_fused_kernel<false>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
                            intr, weights, ii, jj, wide);
         hipLaunchKernelGGL(ba_schur_fused_kernel<true>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
                            intr, weights, ii, jj, wide);
-        if (wide) {  // fewer, larger workgroups (512 threads, all rows of the slot resident in LDS)
-          // pixel splits: every split costs one fp64 atomic per output entry (measured sweet spots)
-          int nsw = 256 / (v.M > 0 ? v.M : 1);
-          nsw = nsw < 2 ? 2 : (nsw > tiles ? tiles : nsw);
-          hipLaunchKernelGGL((ba_schur_wide_kernel<SW_MID, 2, 1, 1>), dim3(v.M, nsw, 1), dim3(64 * SW_NW), 0, s, v,
-                             poses, disps, intr, weights, ii, jj);
+        if (wide) {  // dense slots: SYRK straight from the E rows the linearisation wrote (v.Ebuf)
+          const int stages = v.HW / SY_TPX;
+          int nsw = 256 / (v.M > 0 ? v.M : 1);  // pixel splits: each costs one fp64 atomic per output entry
+          nsw = nsw < 2 ? 2 : (nsw > stages ? stages : nsw);
+          hipLaunchKernelGGL((ba_syrk_kernel<SW_MID, 2, 1, 1>), dim3(v.M, nsw, 1), dim3(512), 0, s, v);
           int nsb = 256 / (4 * (v.M > 0 ? v.M : 1));
-          nsb = nsb < 2 ? 2 : (nsb > tiles ? tiles : nsb);
-          hipLaunchKernelGGL((ba_schur_wide_kernel<SW_BIG, 1, 2, 4>), dim3(v.M, nsb, 4), dim3(64 * SW_NW), 0, s, v,
-                             poses, disps, intr, weights, ii, jj);
+          nsb = nsb < 2 ? 2 : (nsb > stages ? stages : nsb);
+          hipLaunchKernelGGL((ba_syrk_kernel<SW_BIG, 1, 2, 4>), dim3(v.M, nsb, 4), dim3(512), 0, s, v);
         }
       }
       break;
