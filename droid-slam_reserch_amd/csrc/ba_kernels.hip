@@ -1085,8 +1085,11 @@ constexpr int SY_TPX = 32;  // pixels per stage
 
 template <int ROWS, int MINWG, int CLS, int NSHARE>
 __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
-  constexpr int NW = 8, NRT = ROWS / 16;
-  constexpr int MAXT = ((NRT * (NRT + 1) / 2 + NSHARE - 1) / NSHARE + NW - 1) / NW;
+  // Output is processed in 32x32 super-tiles (2x2 MFMA tiles): one A fragment serves two B fragments and
+  // vice versa, which halves the LDS operand traffic (with one 16x16 tile per step the LDS reads --
+  // 512 B per MFMA -- cost as much time as the MFMAs themselves).
+  constexpr int NW = 8, NST = (ROWS / 16 + 1) / 2;
+  constexpr int MAXS = ((NST * (NST + 1) / 2 + NSHARE - 1) / NSHARE + NW - 1) / NW;  // super-tiles per wave
   constexpr int BUF_FLOATS = (ROWS + 8) * SY_TPX;       // + the Q row, rounded up to a DMA group of 8 rows
   constexpr int MAXSLOT = ((ROWS + 8) / 8 + NW - 1) / NW;  // DMA instructions per wave and stage
   __shared__ __attribute__((aligned(16))) float EB[2][BUF_FLOATS];
@@ -1104,12 +1107,13 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
   const int spw = (stages_total + gridDim.y - 1) / gridDim.y;
   const int st_beg = blockIdx.y * spw, st_end = min(stages_total, st_beg + spw);
   if (st_beg >= st_end) return;
-  const int ntr = (R + 1 + 15) / 16;
-  const int ntiles_all = ntr * (ntr + 1) / 2;
-  const int tshare = (ntiles_all + NSHARE - 1) / NSHARE;
-  const int tile0 = (int)blockIdx.z * tshare;
-  const int ntiles = min(tshare, ntiles_all - tile0);
-  if (ntiles <= 0) return;
+  const int ntr = (R + 1 + 15) / 16;              // 16-row tiles
+  const int nst = (ntr + 1) / 2;                  // 32-row super-tile rows
+  const int nsup_all = nst * (nst + 1) / 2;       // lower triangle of super-tiles
+  const int sshare = (nsup_all + NSHARE - 1) / NSHARE;
+  const int sup0 = (int)blockIdx.z * sshare;      // first super-tile of this workgroup
+  const int nsup = min(sshare, nsup_all - sup0);
+  if (nsup <= 0) return;
 
   // staging plan: DMA instruction k covers rows 8k..8k+7 (lane >> 3), 16-byte slot lane & 7 of each
   const int nrows = R + 2;
@@ -1138,10 +1142,28 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
   };
 
   const int r = lane & 15, g = lane >> 4;
-  f32x4 acc[MAXT];
+  f32x4 acc[MAXS][4];  // [super-tile][2*ia + ib]: tile (2*sa + ia, 2*sb + ib)
 #pragma unroll
-  for (int t = 0; t < MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < MAXS; u++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[u][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // LDS float offsets of this lane's operand rows per super-tile (constant over the stages); row + 16
+  // keeps (row & 7), so the second tile row of a super-tile sits exactly 16 rows further.  A second
+  // row block past the slot's tiles is folded onto the first (its results are never read).
+  int offa[MAXS], offb[MAXS], da[MAXS], db[MAXS];
+#pragma unroll
+  for (int u = 0; u < MAXS; u++) {
+    int sa, sb;
+    tri_coords(min(sup0 + wave + NW * u, nsup_all - 1), sa, sb);
+    const int ra = 32 * sa + r, rb = 32 * sb + r;
+    offa[u] = ra * SY_TPX + 4 * (g ^ (ra & 7));
+    offb[u] = rb * SY_TPX + 4 * (g ^ (rb & 7));
+    da[u] = (2 * sa + 1 < ntr) ? 16 * SY_TPX : 0;
+    db[u] = (2 * sb + 1 < ntr) ? 16 * SY_TPX : 0;
+  }
+  const int nmine = (max(nsup - wave, 0) + NW - 1) / NW;  // super-tiles of this wave
   const int qrow = R + 1;
+  const int offq = qrow * SY_TPX + 4 * (g ^ (qrow & 7));
   issue_stage(st_beg, 0);
   for (int st = st_beg; st < st_end; st++) {
     const int buf = (st - st_beg) & 1;
@@ -1149,53 +1171,62 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
     __builtin_amdgcn_s_barrier();                     // everybody's has; stage st-1 is consumed
     if (st + 1 < st_end) issue_stage(st + 1, buf ^ 1);
     const float* Eb = EB[buf];
-    f32x4 q4[2];
+    // chunk index of k-half h is 4h + g: slot (4h + g) ^ (row & 7) = (g ^ (row & 7)) ^ 4h, i.e. the two
+    // halves of a row sit 16 floats apart: XOR 16 on the float offset
+    f32x4 qv[2];
+    qv[0] = *reinterpret_cast<const f32x4*>(&Eb[offq]);
+    qv[1] = *reinterpret_cast<const f32x4*>(&Eb[offq ^ 16]);
 #pragma unroll
-    for (int s2 = 0; s2 < 2; s2++)
-      q4[s2] = *reinterpret_cast<const f32x4*>(&Eb[qrow * SY_TPX + 4 * ((4 * s2 + g) ^ (qrow & 7))]);
+    for (int u = 0; u < MAXS; u++) {
+      if (u < nmine) {  // wave-uniform; four independent accumulation chains per super-tile
 #pragma unroll
-    for (int t = 0; t < MAXT; t++) {
-      if (wave + NW * t < ntiles) {
-        int ta, tb;
-        tri_coords(tile0 + wave + NW * t, ta, tb);
-        const int ra = 16 * ta + r, rb = 16 * tb + r;
-        f32x4 c = acc[t];
+        for (int h = 0; h < 2; h++) {
+          f32x4 a0 = *reinterpret_cast<const f32x4*>(&Eb[offa[u] ^ (16 * h)]);
+          f32x4 a1 = *reinterpret_cast<const f32x4*>(&Eb[(offa[u] + da[u]) ^ (16 * h)]);
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Eb[offb[u] ^ (16 * h)]);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Eb[(offb[u] + db[u]) ^ (16 * h)]);
+          a0 = a0 * qv[h];
+          a1 = a1 * qv[h];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-          f32x4 av = *reinterpret_cast<const f32x4*>(&Eb[ra * SY_TPX + 4 * ((4 * s2 + g) ^ (ra & 7))]);
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(&Eb[rb * SY_TPX + 4 * ((4 * s2 + g) ^ (rb & 7))]);
-          av = av * q4[s2];
-#pragma unroll
-          for (int e = 0; e < 4; e++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], c, 0, 0, 0);
+          for (int e = 0; e < 4; e++) {
+            acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc[u][0], 0, 0, 0);
+            acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b1[e], acc[u][1], 0, 0, 0);
+            acc[u][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b0[e], acc[u][2], 0, 0, 0);
+            acc[u][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc[u][3], 0, 0, 0);
+          }
         }
-        acc[t] = c;
       }
     }
   }
   // ---- fold the accumulators into the dense system (A - S): lower triangle, fp64 atomics
 #pragma unroll
-  for (int t = 0; t < MAXT; t++) {
-    if (wave + NW * t < ntiles) {
-      int ta, tb;
-      tri_coords(tile0 + wave + NW * t, ta, tb);
+  for (int u = 0; u < MAXS; u++) {
+    if (u < nmine) {
+      int sa, sb;
+      tri_coords(sup0 + wave + NW * u, sa, sb);
 #pragma unroll
-      for (int x = 0; x < 4; x++) {
-        const int li = 16 * ta + 4 * g + x;  // row of the slot (A side)
-        const int lj = 16 * tb + r;          // B side, always an E row
-        if (lj >= R || li > R) continue;
-        const double val = -(double)acc[t][x];
-        const int gj = 6 * v.ent_pose[e0 + lj / 6] + lj % 6;
-        if (li == R) {  // w row: reduced rhs
-          atomicAdd(&v.sys[(size_t)v.n * v.ld + gj], val);
-          continue;
-        }
-        const int gi = 6 * v.ent_pose[e0 + li / 6] + li % 6;
-        if (ta == tb) {  // diagonal tile: both (li,lj) and (lj,li) are computed
-          if (gi >= gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
-        } else {  // the mirror element is not computed: fold it into the lower triangle
-          if (gi > gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
-          else if (gi < gj) atomicAdd(&v.sys[(size_t)gj * v.ld + gi], val);
-          else atomicAdd(&v.sys[(size_t)gi * v.ld + gj], 2.0 * val);
+      for (int q = 0; q < 4; q++) {
+        const int ta = 2 * sa + (q >> 1), tb = 2 * sb + (q & 1);
+        if (ta >= ntr || tb > ta) continue;  // outside the slot / strict upper tile of a diagonal super-tile
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+          const int li = 16 * ta + 4 * g + x;  // row of the slot (A side)
+          const int lj = 16 * tb + r;          // B side, always an E row
+          if (lj >= R || li > R) continue;
+          const double val = -(double)acc[u][q][x];
+          const int gj = 6 * v.ent_pose[e0 + lj / 6] + lj % 6;
+          if (li == R) {  // w row: reduced rhs
+            atomicAdd(&v.sys[(size_t)v.n * v.ld + gj], val);
+            continue;
+          }
+          const int gi = 6 * v.ent_pose[e0 + li / 6] + li % 6;
+          if (ta == tb) {  // diagonal tile: both (li,lj) and (lj,li) are computed
+            if (gi >= gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
+          } else {  // the mirror element is not computed: fold it into the lower triangle
+            if (gi > gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
+            else if (gi < gj) atomicAdd(&v.sys[(size_t)gj * v.ld + gi], val);
+            else atomicAdd(&v.sys[(size_t)gi * v.ld + gj], 2.0 * val);
+          }
         }
       }
     }
