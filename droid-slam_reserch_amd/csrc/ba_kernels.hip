@@ -112,13 +112,12 @@ struct SlotMeta {
 
 constexpr int SF_TP = 64;             // pixels per LDS tile; 4 threads per pixel split the edges
 constexpr int SF_RB = 96;             // rows per block (16 entries)
-// Dense slots (more than 16 entries) are served by the wide kernels further down.
-constexpr int SW_PITCH = SF_TP + 4;
-constexpr int SW_NW = 8;      // waves per workgroup = threads per pixel in the staging phase
-constexpr int SW_MID = 208;   // rows (incl. the w row) served by the two-per-CU variant
+// Dense slots (more than 16 entries) are served by the SYRK-only kernel further down.
+constexpr int SW_MID = 208;   // rows (incl. the w row) served by the two-workgroups-per-CU variant
 constexpr int SW_BIG = 512;   // rows served by the one-per-CU variant (85 entries)
 
-// which kernel serves a slot: 0 = single 96-row block, 1/2 = wide kernels, 3 = block pairs.
+// which kernel serves a slot: 0 = single 96-row block, 1/2 = SYRK-only kernel (E rows from v.Ebuf),
+// 3 = block pairs.
 // `wide` is a host-side decision (mean out-degree of the graph): sparse graphs skip the two wide
 // launches altogether and leave their few dense slots to the block-pair kernel
 __device__ __forceinline__ int schur_class(int rows, int nedges, int wide) {
@@ -872,18 +871,6 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
 #endif
 }
 
-// ------------------------------------------------------------------------------------------
-// Dense slots (more than 16 entries: global BA of a well connected graph, or the per-rank shard of
-// an edge-sharded run where every local frame keeps ALL its edges).  The block-pair scheme above
-// restages the E rows once per pair of 96-row blocks; here ALL rows of the slot (up to ROWS) sit
-// in LDS at once, staged once per 64-pixel tile by 8 waves, and the lower triangle of
-// S = B~ B~^T is accumulated in registers.  The MFMA operands are read with 16-byte LDS loads:
-// row pitch 68 floats (16-byte aligned rows, conflict-free for 8 consecutive rows) and a
-// permuted K order (k-step (s,e) of lane group g = pixel 16s+4g+e of the tile, identical for both
-// operands).  ROWS = 208 (two workgroups per CU) and 512 (one; four workgroups share the output
-// tiles of a (slot, pixel range): each stages all rows but accumulates only its contiguous share,
-// which bounds the accumulator registers and supplies the parallelism a 32-slot shard lacks).
-// ------------------------------------------------------------------------------------------
 // (ta, tb), tb <= ta, of index ti in the row-major enumeration of a lower triangle
 __device__ __forceinline__ void tri_coords(int ti, int& ta, int& tb) {
   int a = (int)((sqrtf(8.0f * (float)ti + 1.0f) - 1.0f) * 0.5f);
@@ -893,186 +880,12 @@ __device__ __forceinline__ void tri_coords(int ti, int& ta, int& tb) {
   tb = ti - a * (a + 1) / 2;
 }
 
-template <int ROWS, int MINWG, int CLS, int NSHARE>
-__global__ __launch_bounds__(64 * SW_NW, MINWG) void ba_schur_wide_kernel(
-    BaView v, const float* __restrict__ poses, const float* __restrict__ disps,
-    const float* __restrict__ intrinsics, const float* __restrict__ weights,
-    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj) {
-  constexpr int NRT = ROWS / 16;
-  constexpr int MAXT = ((NRT * (NRT + 1) / 2 + NSHARE - 1) / NSHARE + SW_NW - 1) / SW_NW;
-  __shared__ __attribute__((aligned(16))) float EA[ROWS * SW_PITCH];
-  __shared__ float SP[SW_NW * 6 * SF_TP];  // partial self rows of the eight edge subsets
-  __shared__ SlotMeta sm;
-  if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
-  const int m = v.order[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int HW = v.HW, W = v.W;
-  const int e0 = v.ent_ptr[m], nent = v.ent_ptr[m + 1] - e0;
-  if (nent == 0) return;
-  const int R = 6 * nent;  // E rows; row R is the w row
-  const int x_beg = v.seg_ptr[m], nedges = v.seg_ptr[m + 1] - x_beg;
-  if (schur_class(R + 1, nedges, 1) != CLS) return;
-  const int f = v.kx[m];
-  const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
-  const int tiles_total = (HW + SF_TP - 1) / SF_TP;
-  const int tpw = (tiles_total + gridDim.y - 1) / gridDim.y;
-  const int tile_beg = blockIdx.y * tpw, tile_end = min(tiles_total, tile_beg + tpw);
-  if (tile_beg >= tile_end) return;
-  const int ntr = (R + 1 + 15) / 16;           // row tiles
-  const int ntiles_all = ntr * (ntr + 1) / 2;  // lower triangle incl. the diagonal tiles
-  const int tshare = (ntiles_all + NSHARE - 1) / NSHARE;
-  const int tile0 = (int)blockIdx.z * tshare;         // first output tile of this workgroup
-  const int ntiles = min(tshare, ntiles_all - tile0);
-  if (ntiles <= 0) return;
-  const bool has_self = (v.ent_row[e0] < v.M);  // the self row, when present, is entry 0
-  const int pixl = tid & (SF_TP - 1), part = wave;
-  load_slot_meta(sm, v, poses, jj, f, x_beg, nedges, has_self ? 1 : 0);
-
-  constexpr int PF = (CLS == 2) ? 8 : 4;  // prefetched edges per thread (its first PF)
-  float pf_q = 0.f, pf_d = 0.f, pf_wr = 0.f, pf_w[2 * PF];
-  auto prefetch = [&](int tile) {
-    const int k = tile * SF_TP + pixl;
-    const bool ok = (tile < tile_end) && (k < HW);
-    pf_q = ok ? v.Q[(size_t)m * HW + k] : 0.f;
-    pf_d = ok ? disps[(size_t)f * HW + k] : 0.f;
-    pf_wr = (ok && part == SW_NW - 1) ? v.w[(size_t)m * HW + k] : 0.f;  // the w row is written by the last wave
-#pragma unroll
-    for (int u = 0; u < PF; u++) {
-      const int x = part + SW_NW * u;
-      const bool okx = ok && x < nedges;
-      const float* wg = weights + (size_t)(okx ? sm.e[x] : 0) * 2 * HW;
-      pf_w[2 * u] = okx ? wg[k] : 0.f;
-      pf_w[2 * u + 1] = okx ? wg[HW + k] : 0.f;
-    }
-  };
-
-  f32x4 acc[MAXT];
-#pragma unroll
-  for (int t = 0; t < MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  prefetch(tile_beg);
-  for (int tile = tile_beg; tile < tile_end; tile++) {
-    const int k = tile * SF_TP + pixl;
-    const bool pok = k < HW;
-    const float sq = sqrtf(pf_q), disp = pf_d, cur_wr = pf_wr;
-    float cur_w[2 * PF];
-#pragma unroll
-    for (int u = 0; u < 2 * PF; u++) cur_w[u] = pf_w[u];
-    __syncthreads();  // previous tile consumed
-    // ---- stage all E rows of the slot for the 64 pixels of the tile (scaled by sqrt(Q))
-    float selfacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int x = part; x < nedges; x += SW_NW) {  // the eight waves take the edges round-robin
-      const int a = sm.ent[x];
-      if (!(a >= 0 || has_self)) continue;
-      const Rel T = meta_rel(sm, x);
-      float eij[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (pok) {
-        float wu_raw, wv_raw;
-        const int u = x / SW_NW;  // this thread's u-th edge
-        if (u < PF) {
-          wu_raw = cur_w[0];
-          wv_raw = cur_w[1];
-#pragma unroll
-          for (int uu = 1; uu < PF; uu++)
-            if (u == uu) {
-              wu_raw = cur_w[2 * uu];
-              wv_raw = cur_w[2 * uu + 1];
-            }
-        } else {
-          const float* wg = weights + (size_t)sm.e[x] * 2 * HW;
-          wu_raw = wg[k];
-          wv_raw = wg[HW + k];
-        }
-        e_row(K, T, sm.flag[x] != 0, k, W, disp, wu_raw, wv_raw, eij);
-      }
-      if (has_self) {  // Ei = -sum_e Adj^T Eij (dk:325-326, :1402)
-        float eii[6];
-        adj_se3(T.t, T.q, eij, eii);
-#pragma unroll
-        for (int n = 0; n < 6; n++) selfacc[n] -= eii[n];
-      }
-      if (a >= 0) {
-#pragma unroll
-        for (int n = 0; n < 6; n++) EA[(6 * a + n) * SW_PITCH + pixl] = eij[n] * sq;
-      }
-    }
-    if (has_self) {  // eight partial sums per pixel, combined in a fixed order
-#pragma unroll
-      for (int n = 0; n < 6; n++) SP[(part * 6 + n) * SF_TP + pixl] = selfacc[n];
-      __syncthreads();
-      if (part < 6) {
-        float sum = 0.f;
-#pragma unroll
-        for (int q = 0; q < SW_NW; q++) sum += SP[(q * 6 + part) * SF_TP + pixl];
-        EA[part * SW_PITCH + pixl] = sum * sq;
-      }
-    }
-    if (part == SW_NW - 1) EA[R * SW_PITCH + pixl] = cur_wr * sq;  // the w row: w sqrt(Q)
-    // rows R+1 .. 16*ntr-1 are never written: they only feed outputs that the fold discards
-    __syncthreads();
-    prefetch(tile + 1);
-    // ---- SYRK of the tile: wave w owns output tiles tile0 + w, tile0 + w + 8, ... of the lower triangle
-    {
-      const int r = lane & 15, g = lane >> 4;
-#pragma unroll
-      for (int t = 0; t < MAXT; t++) {
-        if (wave + SW_NW * t < ntiles) {
-          int ta, tb;
-          tri_coords(tile0 + wave + SW_NW * t, ta, tb);
-          const float* pa = &EA[(16 * ta + r) * SW_PITCH + 4 * g];
-          const float* pb = &EA[(16 * tb + r) * SW_PITCH + 4 * g];
-          f32x4 c = acc[t];
-#pragma unroll
-          for (int s4 = 0; s4 < SF_TP; s4 += 16) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(pa + s4);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + s4);
-#pragma unroll
-            for (int e = 0; e < 4; e++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], c, 0, 0, 0);
-          }
-          acc[t] = c;
-        }
-      }
-    }
-  }
-  // ---- fold the accumulators into the dense system (A - S): lower triangle, fp64 atomics
-  {
-    const int r = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < MAXT; t++) {
-      if (wave + SW_NW * t < ntiles) {
-        int ta, tb;
-        tri_coords(tile0 + wave + SW_NW * t, ta, tb);
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-          const int li = 16 * ta + 4 * g + x;  // row of the slot (A side)
-          const int lj = 16 * tb + r;          // B side, always an E row
-          if (lj >= R || li > R) continue;
-          const double val = -(double)acc[t][x];
-          const int gj = 6 * v.ent_pose[e0 + lj / 6] + lj % 6;
-          if (li == R) {  // w row: reduced rhs
-            atomicAdd(&v.sys[(size_t)v.n * v.ld + gj], val);
-            continue;
-          }
-          const int gi = 6 * v.ent_pose[e0 + li / 6] + li % 6;
-          if (ta == tb) {  // diagonal tile: both (li,lj) and (lj,li) are computed
-            if (gi >= gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
-          } else {  // the mirror element is not computed: fold it into the lower triangle
-            if (gi > gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
-            else if (gi < gj) atomicAdd(&v.sys[(size_t)gj * v.ld + gi], val);
-            else atomicAdd(&v.sys[(size_t)gi * v.ld + gj], 2.0 * val);
-          }
-        }
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // Dense slots, SYRK only.  With 17..85 entries per slot the accumulators of S = B Q B^T no longer
 // fit one CU, so several workgroups share the output tiles of a (slot, pixel range) and each
-// needs ALL rows of the slot: recomputing the E rows per share (ba_schur_wide_kernel) repeats the
-// whole staging arithmetic 2-4 times and alternates VALU and MFMA phases.  For such graphs the
+// needs ALL rows of the slot: recomputing the E rows per share repeats the
+// whole staging arithmetic 2-4 times and alternates VALU and MFMA phases (an earlier kernel of this
+// file did exactly that: 0.50 ms for the Schur complement of an 8-way edge shard).  For such graphs the
 // linearisation writes the unscaled E rows once (v.Ebuf) and this kernel only streams them:
 // 32-pixel stages of all rows (+ the w row and the Q row) arrive by LDS-DMA (global_load_lds_dwordx4
 // from inline asm, two buffers, the DMA of stage s+1 in flight while stage s is multiplied), the

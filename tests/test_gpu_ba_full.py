@@ -57,6 +57,16 @@ def test_cfg5_stereo_96x128_matches_oracle(backends, oracle, synth):
     _parity(backends, oracle, synth.make_config("cfg5"), 1, "cfg5")
 
 
+def test_dense_graph_syrk_kernels_match_oracle(backends, oracle, synth):
+    """36 keyframes with ~37 edges each: every depth slot has more than 34 entries (> 208 E rows), which
+    takes the path of edge-sharded ranks: the linearisation writes the E rows once and the SYRK-only
+    Schur kernel (512-row variant, output tiles shared by four workgroups) streams them."""
+    p = synth.make_ba_problem(N=36, E=1200, H=16, W=32, seed=77, lm=1e-4, ep=0.1)
+    deg = np.bincount(p.ii, minlength=36)
+    assert deg.min() >= 30 and len(p.ii) >= 12 * p.eta.shape[0]
+    _parity(backends, oracle, p, 2, "dense 36kf/1200e")
+
+
 def test_cfg3_edge_permutation_invariance(backends, cfg3):
     """The solution does not depend on the order of the edge list (only summation order changes)."""
     torch = _torch()
