@@ -40,6 +40,8 @@ struct BaView {
   float* Ebuf;             // dense graphs only (`wide`): unscaled E rows [6*(M+E)][HW], row 6*(entry)+n, written by
                            // the linearisation and consumed by the SYRK-only Schur kernel
   int wide;                // host decision: mean out-degree >= 12 (dense global BA, edge-sharded ranks)
+  int zsplit;              // linearisation: workgroups per (slot, pixel chunk), each takes a range of the slot's edges
+  float* zpart;            // zsplit > 1: [zsplit][M][8][HW] partial C, w and self-row sums of those workgroups
   double* sys;             // [n+1][ld] reduced camera system, lower triangle, row n = rhs
   double* xsol;            // [ld] solve scratch / solution
   float* dx;               // [P][6]
@@ -82,6 +84,15 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.wide = (M > 0 && (long)E >= 12l * M && (v.HW % 32) == 0) ? 1 : 0;
   v.Ebuf = nullptr;   // ... except for dense graphs, where the recomputation would be repeated per output share
   if (v.wide) v.Ebuf = static_cast<float*>(take(sizeof(float) * (6 * ((size_t)M + E) * v.HW + 64)));
+  // few depth slots (edge-sharded ranks, small windows): split every slot's edges over several
+  // workgroups so that the linearisation still fills the chip
+  v.zsplit = 1;
+  if (M > 0) {
+    const int z = 1536 / (M * v.nch);
+    v.zsplit = z < 1 ? 1 : (z > 8 ? 8 : z);
+  }
+  v.zpart = nullptr;
+  if (v.zsplit > 1) v.zpart = static_cast<float*>(take(sizeof(float) * ((size_t)v.zsplit * M * 8 * v.HW + 64)));
   v.sys = static_cast<double*>(take(sizeof(double) * ((size_t)(v.n + 1) * v.ld + 8)));
   v.xsol = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld + 1)));
   v.dx = static_cast<float*>(take(sizeof(float) * ((size_t)v.n + 8)));

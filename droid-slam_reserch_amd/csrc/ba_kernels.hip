@@ -312,7 +312,8 @@ __global__ __launch_bounds__(1024) void ba_prep_kernel(BaView v, const int64_t* 
 // ------------------------------------------------------------------------------------------
 // EROWS (dense graphs): slots that the SYRK-only Schur kernel will serve also get their UNSCALED E rows
 // written to v.Ebuf (row 6*entry + n; the self row Ei = -sum_e Adj^T Eij is accumulated per pixel).
-template <bool DEPTH, bool EROWS>
+// ZSPLIT: gridDim.z workgroups share a (slot, chunk), each taking a range of the slot's edges.
+template <bool DEPTH, bool EROWS, bool ZSPLIT>
 __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
     BaView v, const float* __restrict__ poses, const float* __restrict__ disps,
     const float* __restrict__ intrinsics, const float* __restrict__ disps_sens,
@@ -337,6 +338,13 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
     if (i0 < 0 || i0 >= v.nbuf || j0 < 0 || j0 >= v.nbuf) return;
   }
   const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  // this workgroup's range of the slot's edges (gridDim.z workgroups per (slot, chunk))
+  int xs = xb, xend = xe;
+  if (DEPTH && ZSPLIT) {
+    const int per = (xe - xb + (int)gridDim.z - 1) / (int)gridDim.z;
+    xs = min(xe, xb + (int)blockIdx.z * per);
+    xend = min(xe, xs + per);
+  }
 
   // E-row emission for this slot?
   bool emit = false, has_self = false;
@@ -381,10 +389,11 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
     }
   };
   int buf = 0;
-  for (int x = xb; x < xe; x++) {
-    if (DEPTH && ((x - xb) % SLOT_MAXE) == 0) {  // (re)load the metadata chunk of this slot
-      if (x > xb) __syncthreads();
-      load_slot_meta(sm, v, poses, jj, f, x, min(SLOT_MAXE, xe - x), (EROWS && has_self) ? 1 : 0);
+  for (int x = xs; x < xend; x++) {
+    if (DEPTH && (x == xs || ((x - xb) % SLOT_MAXE) == 0)) {  // (re)load the metadata chunk holding edge x
+      if (x > xs) __syncthreads();
+      const int cb = xb + ((x - xb) / SLOT_MAXE) * SLOT_MAXE;
+      load_slot_meta(sm, v, poses, jj, f, cb, min(SLOT_MAXE, xe - cb), (EROWS && has_self) ? 1 : 0);
     }
     const int xl = DEPTH ? (x - xb) % SLOT_MAXE : 0;
     const int e = DEPTH ? sm.e[xl] : x;
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
         for (int c = 0; c < 4; c++) in_cur[p][c] = in_nxt[p][c];
     }
     have_next = false;
-    if (DEPTH && x + 1 < xe && xl + 1 < SLOT_MAXE) {
+    if (DEPTH && x + 1 < xend && xl + 1 < SLOT_MAXE) {
       fetch_edge(sm.e[xl + 1], in_nxt);
       have_next = true;
     }
@@ -476,6 +485,20 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
     buf ^= 1;  // double buffer: one barrier per edge
   }
 
+  if (DEPTH && ZSPLIT) {
+    // partial sums of this edge range; ba_lin_finish_kernel adds them up in a fixed order
+#pragma unroll
+    for (int p = 0; p < LIN_PPT; p++) {
+      if (pix[p] < HW) {
+        float* zp = v.zpart + (((size_t)blockIdx.z * v.M + m) * 8) * HW + pix[p];
+        zp[0] = Cacc[p];
+        zp[(size_t)HW] = wacc[p];
+#pragma unroll
+        for (int n = 0; n < 6; n++) zp[(size_t)(2 + n) * HW] = selfacc[p][n];
+      }
+    }
+    return;
+  }
   if (DEPTH) {
     const float alpha = 0.05f;  // dk:1396
 #pragma unroll
@@ -494,6 +517,37 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
           for (int n = 0; n < 6; n++) v.Ebuf[(size_t)(6 * e0 + n) * HW + k] = selfacc[p][n];
         }
       }
+    }
+  }
+}
+
+// zsplit > 1: C, w (-> Q, w) and the self rows from the partial sums of the edge ranges
+__global__ __launch_bounds__(256) void ba_lin_finish_kernel(BaView v, const float* __restrict__ disps,
+                                                            const float* __restrict__ disps_sens,
+                                                            const float* __restrict__ eta) {
+  if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
+  const int m = blockIdx.x, HW = v.HW;
+  const int k = blockIdx.y * 256 + threadIdx.x;
+  if (k >= HW) return;
+  const int f = v.kx[m];
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < v.zsplit; z++) {
+    const float* zp = v.zpart + (((size_t)z * v.M + m) * 8) * HW + k;
+#pragma unroll
+    for (int q = 0; q < 8; q++) s[q] += zp[(size_t)q * HW];
+  }
+  const float alpha = 0.05f;  // dk:1396
+  const size_t o = (size_t)m * HW + k;
+  const float sens = disps_sens[(size_t)f * HW + k], disp = disps[(size_t)f * HW + k];
+  const float ms = sens > 0.f ? 1.f : 0.f;
+  v.Q[o] = 1.0f / (s[0] + ms * alpha + (1.f - ms) * eta[o]);  // dk:1398, :1400
+  v.w[o] = s[1] - ms * alpha * (disp - sens);                  // dk:1399
+  if (v.wide) {
+    const int e0 = v.ent_ptr[m], nent = v.ent_ptr[m + 1] - e0;
+    const int cls = schur_class(6 * nent + 1, v.seg_ptr[m + 1] - v.seg_ptr[m], 1);
+    if ((cls == 1 || cls == 2) && nent > 0 && v.ent_row[e0] < v.M) {
+#pragma unroll
+      for (int n = 0; n < 6; n++) v.Ebuf[(size_t)(6 * e0 + n) * HW + k] = s[2 + n];
     }
   }
 }
@@ -1177,16 +1231,22 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
   switch (stage) {
     case 0:
       (void)hipMemsetAsync(v.sys, 0, sizeof(double) * (size_t)(v.n + 1) * v.ld, s);
-      if (depth)
-        if (v.wide)
-          hipLaunchKernelGGL((ba_lin_kernel<true, true>), dim3(v.M, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
-                             disps, intr, sens, targets, weights, eta, ii, jj);
+      if (depth) {
+        const dim3 g(v.M, v.nch, v.zsplit), b(LIN_THREADS);
+        if (v.wide && v.zsplit > 1)
+          hipLaunchKernelGGL((ba_lin_kernel<true, true, true>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj);
+        else if (v.wide)
+          hipLaunchKernelGGL((ba_lin_kernel<true, true, false>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj);
+        else if (v.zsplit > 1)
+          hipLaunchKernelGGL((ba_lin_kernel<true, false, true>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj);
         else
-          hipLaunchKernelGGL((ba_lin_kernel<true, false>), dim3(v.M, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
-                             disps, intr, sens, targets, weights, eta, ii, jj);
-      else if (v.E > 0)
-        hipLaunchKernelGGL((ba_lin_kernel<false, false>), dim3(v.E, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
+          hipLaunchKernelGGL((ba_lin_kernel<true, false, false>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj);
+        if (v.zsplit > 1)
+          hipLaunchKernelGGL(ba_lin_finish_kernel, dim3(v.M, (v.HW + 255) / 256), dim3(256), 0, s, v, disps, sens, eta);
+      } else if (v.E > 0) {
+        hipLaunchKernelGGL((ba_lin_kernel<false, false, false>), dim3(v.E, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
                            disps, intr, sens, targets, weights, eta, ii, jj);
+      }
       break;
     case 1:
       if (v.E > 0)
