@@ -67,6 +67,14 @@ def test_dense_graph_syrk_kernels_match_oracle(backends, oracle, synth):
     _parity(backends, oracle, p, 2, "dense 36kf/1200e")
 
 
+def test_dense_graph_block_pair_kernel_matches_oracle(backends, oracle, synth):
+    """Same kind of graph at a resolution that is not a multiple of 32 pixels: the E-row cache is
+    not used and the slots (21-29 entries, up to 175 rows) go through the 96-row block-pair Schur kernel."""
+    p = synth.make_ba_problem(N=30, E=720, H=15, W=20, seed=78, lm=1e-4, ep=0.1)
+    assert np.bincount(p.ii, minlength=30).min() >= 17
+    _parity(backends, oracle, p, 2, "dense 30kf/720e 15x20")
+
+
 def test_cfg3_edge_permutation_invariance(backends, cfg3):
     """The solution does not depend on the order of the edge list (only summation order changes)."""
     torch = _torch()
