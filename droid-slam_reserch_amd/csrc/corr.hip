@@ -599,17 +599,18 @@ __global__ __launch_bounds__(ALT_THREADS, 2) void altcorr_forward_tiled(const fl
 // flops (2.25x for a smooth flow field) on a pipe that is otherwise idle.  A tile whose boxes do
 // not fit (incoherent coordinates) is evaluated per query.
 #ifdef AM_STAMPS
-// Diagnostic build only: s_memtime stamps per wave of the first 64 workgroups of edge (0,0).
-__device__ unsigned long long g_am_stamps[64 * 4 * 32];
+#define AM_LIN (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))
+// Diagnostic build only: s_memtime stamps per wave of the first 768 workgroups (three per CU).
+__device__ unsigned long long g_am_stamps[768 * 4 * 32];
 #define AMSTAMP(slot)                                                                              \
   do {                                                                                             \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0)           \
-      g_am_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    if ((threadIdx.x & 63) == 0 && AM_LIN < 768)                                                    \
+      g_am_stamps[(AM_LIN * 4 + (threadIdx.x >> 6)) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #define AMNOTE(slot, v)                                                                            \
   do {                                                                                             \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0)           \
-      g_am_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (slot)] = (unsigned long long)(v);  \
+    if ((threadIdx.x & 63) == 0 && AM_LIN < 768)                                                    \
+      g_am_stamps[(AM_LIN * 4 + (threadIdx.x >> 6)) * 32 + (slot)] = (unsigned long long)(v);  \
   } while (0)
 #else
 #define AMSTAMP(slot) do { } while (0)
@@ -662,6 +663,8 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
   const int H1W1 = H1 * W1;
 
   AMSTAMP(0);
+  AMNOTE(12, __builtin_amdgcn_s_getreg((31 << 11) | 4));   // HW_ID: which CU this workgroup runs on
+  AMNOTE(13, __builtin_amdgcn_s_getreg((31 << 11) | 20));  // XCC_ID
   // --- GEMM role: lane (row = lane & 15, g = lane >> 4); row = query (sy, sx) of the sub-tile
   const int row = lane & 15, g = lane >> 4;
   const int gqx = tx * AM_TX + 4 * wave + (row & 3), gqy = ty * AM_TY + (row >> 2);
@@ -1050,7 +1053,7 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_pyramid_mfma(Al
 
 #ifdef AM_STAMPS
 extern "C" int droid_debug_am_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_am_stamps), sizeof(unsigned long long) * 64 * 4 * 32);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_am_stamps), sizeof(unsigned long long) * 768 * 4 * 32);
 }
 #endif
 

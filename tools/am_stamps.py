@@ -19,9 +19,9 @@ a1 = pyr[0][ii].contiguous(); a2 = pyr[lvl][jj].contiguous(); ca = (c[:, None] /
 for _ in range(3):
     db.altcorr_forward(a1, a2, ca, r); torch.cuda.synchronize()
 lib = db._lib.load()
-buf = (ctypes.c_ulonglong * (64 * 4 * 32))()
+buf = (ctypes.c_ulonglong * (768 * 4 * 32))()
 lib.droid_debug_am_stamps(buf)
-st = np.array(buf[:], dtype=np.int64).reshape(64, 4, 32)
+st = np.array(buf[:], dtype=np.int64).reshape(768, 4, 32)[:48]
 names = ["coords+box", "plan", "dma0", "kloop", "dwrite", "combine"]
 d = np.diff(st[:, :, :7], axis=2)
 print("level", lvl, "mean per phase (s_memtime ticks):", " ".join(f"{n}={v:.0f}" for n, v in zip(names, d.mean(axis=(0, 1)))),
