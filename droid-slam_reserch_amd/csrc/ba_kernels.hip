@@ -113,7 +113,7 @@ struct SlotMeta {
 constexpr int SF_TP = 64;             // pixels per LDS tile; 4 threads per pixel split the edges
 constexpr int SF_RB = 96;             // rows per block (16 entries)
 // Dense slots (more than 16 entries) are served by the SYRK-only kernel further down.
-constexpr int SW_MID = 208;   // rows (incl. the w row) served by the two-workgroups-per-CU variant
+constexpr int SW_MID = 272;   // rows (incl. the w row) served by the two-workgroups-per-CU variant (45 entries)
 constexpr int SW_BIG = 512;   // rows served by the one-per-CU variant (85 entries)
 
 // which kernel serves a slot: 0 = single 96-row block, 1/2 = SYRK-only kernel (E rows from v.Ebuf),
@@ -1269,7 +1269,7 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
           const int stages = v.HW / SY_TPX;
           int nsw = 256 / (v.M > 0 ? v.M : 1);  // pixel splits: each costs one fp64 atomic per output entry
           nsw = nsw < 2 ? 2 : (nsw > stages ? stages : nsw);
-          hipLaunchKernelGGL((ba_syrk_kernel<SW_MID, 2, 1, 1>), dim3(v.M, nsw, 1), dim3(512), 0, s, v);
+          hipLaunchKernelGGL((ba_syrk_kernel<SW_MID, 4, 1, 2>), dim3(v.M, nsw, 2), dim3(512), 0, s, v);
           int nsb = 256 / (4 * (v.M > 0 ? v.M : 1));
           nsb = nsb < 2 ? 2 : (nsb > stages ? stages : nsb);
           hipLaunchKernelGGL((ba_syrk_kernel<SW_BIG, 1, 2, 4>), dim3(v.M, nsb, 4), dim3(512), 0, s, v);
