@@ -1151,7 +1151,22 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
     if (threadIdx.x < cnt) {
       const int pj = sm.pj[threadIdx.x];
       const bool on = pj > 0 && pj < v.P;  // entries with p <= 0 or p >= P do not feed back
-      for (int n = 0; n < 6; n++) dxs[threadIdx.x][n] = (on && !failed) ? (float)xsol[6 * pj + n] : 0.f;
+      // per edge: c = dx_j - Adj(T_ij) dx_i, so that E_ij . dx_j + E_i . dx_i (E_i = -Adj^T E_ij per edge,
+      // dk:325-326) becomes ONE dot product per (edge, pixel): (Adj^T e) . d = e . (Adj d)
+      float c[6];
+      for (int n = 0; n < 6; n++) c[n] = (on && !failed) ? (float)xsol[6 * pj + n] : 0.f;
+      if (self_on) {
+        const Rel T = meta_rel(sm, threadIdx.x);
+        for (int k = 0; k < 6; k++) {  // (Adj d)_k = (Adj^T e_k) . d
+          float ek[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, col[6];
+          ek[k] = 1.f;
+          adj_se3(T.t, T.q, ek, col);
+          float z = 0.f;
+          for (int n = 0; n < 6; n++) z += col[n] * dxi[n];
+          c[k] -= z;
+        }
+      }
+      for (int n = 0; n < 6; n++) dxs[threadIdx.x][n] = c[n];
       sm.ent[threadIdx.x] = on ? 1 : 0;
     }
     __syncthreads();
@@ -1174,12 +1189,6 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
         float dw = 0.f;
 #pragma unroll
         for (int n = 0; n < 6; n++) dw += eij[n] * dxs[x][n];
-        if (self_on) {
-          float eii[6];
-          adj_se3(T.t, T.q, eij, eii);
-#pragma unroll
-          for (int n = 0; n < 6; n++) dw -= eii[n] * dxi[n];
-        }
         acc[p] += dw;
       }
     }
