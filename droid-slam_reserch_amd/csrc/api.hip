@@ -199,7 +199,7 @@ int droid_ba_solve_update(float* poses, float* disps, const float* intrinsics, c
     return fail(DROID_E_ARG, "ba: null %s", "intrinsics/weights/edges");
   hipStream_t s = (hipStream_t)stream;
   (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
-  launch_chol_solve(v.sys, v.n, v.ld, (double)lm, (double)ep, v.xsol, v.hdr + HDR_CHOL_FAIL, v.bs_flags, s);
+  launch_chol_solve(v.sys, v.n, v.ld, (double)lm, (double)ep, v.xsol, v.hdr + HDR_CHOL_FAIL, v.bs_flags, v.ldiag, s);
   launch_update(v, poses, disps, intrinsics, weights, ii, jj, v.xsol, dx_out, dz_out, motion_only != 0, s);
   return check_hip("ba_solve_update");
 }
@@ -249,9 +249,13 @@ int droid_ba_profile_iteration(float* poses, float* disps, const float* intrinsi
   launch_build_stage(v, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, motion_only != 0, 3, s);
   (void)hipEventRecord(ev[4], s);
   (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
-  launch_chol_factor(v.sys, v.n, v.ld, (double)lm, (double)ep, v.hdr + HDR_CHOL_FAIL, s);
+  if (v.n > 0) {  // presets of x and the hand-off flags, as launch_chol_solve does
+    (void)hipMemsetAsync(v.xsol, 0xFF, sizeof(double) * (size_t)v.n, s);
+    (void)hipMemsetAsync(v.bs_flags, 0xFF, sizeof(int) * chol_flag_words(v.n), s);
+  }
+  launch_chol_factor(v.sys, v.n, v.ld, (double)lm, (double)ep, v.hdr + HDR_CHOL_FAIL, v.bs_flags, v.ldiag, s);
   (void)hipEventRecord(ev[5], s);
-  launch_chol_backsolve(v.sys, v.n, v.ld, v.xsol, v.bs_flags, v.hdr + HDR_CHOL_FAIL, s);
+  launch_chol_backsolve(v.sys, v.n, v.ld, v.xsol, v.bs_flags, v.ldiag, v.hdr + HDR_CHOL_FAIL, s);
   (void)hipEventRecord(ev[6], s);
   launch_update(v, poses, disps, intrinsics, weights, ii, jj, v.xsol, nullptr, nullptr, motion_only != 0, s);
   (void)hipEventRecord(ev[7], s);
@@ -293,11 +297,12 @@ int droid_chol_solve(const double* A, const double* b, double* x, int n, double*
                      int* fail_flag, void* stream) {
   if (n <= 0 || !A || !b || !x || !scratch || !fail_flag) return fail(DROID_E_ARG, "chol_solve: bad %s", "argument");
   hipStream_t s = (hipStream_t)stream;
-  const int ld = (n + 1 + 7) & ~7;
+  const int ld = chol_ld(n);
   (void)hipMemsetAsync(fail_flag, 0, sizeof(int), s);
   launch_chol_pack(A, b, scratch, n, ld, s);
-  int* flags = reinterpret_cast<int*>(scratch + (size_t)(n + 1) * ld);  // tail of the scratch buffer
-  launch_chol_solve(scratch, n, ld, 0.0, 0.0, x, fail_flag, flags, s);
+  double* ldiag = scratch + (size_t)(n + 1) * ld;   // tail of the scratch buffer: diagonal tiles, then flags
+  int* flags = reinterpret_cast<int*>(ldiag + chol_ldiag_doubles(n));
+  launch_chol_solve(scratch, n, ld, 0.0, 0.0, x, fail_flag, flags, ldiag, s);
   return check_hip("chol_solve");
 }
 

@@ -10,6 +10,11 @@ constexpr int LIN_THREADS = 256;
 constexpr int LIN_PPT = 2;                       // pixels per thread per chunk
 constexpr int LIN_CP = LIN_THREADS * LIN_PPT;    // pixels per workgroup chunk
 constexpr int CHOL_NB = 64;                      // Cholesky block size
+// row pitch of the augmented system in doubles: 128-byte rows, so 64-column tiles never share a cache line
+inline int chol_ld(int n) { return (n + 1 + 15) & ~15; }
+// ints of hand-off flags (done[], dver[], abort) and doubles of factored diagonal tiles for an n x n solve
+inline size_t chol_flag_words(int n) { return 2 * ((size_t)(n + 1 + CHOL_NB - 1) / CHOL_NB) + 8; }
+inline size_t chol_ldiag_doubles(int n) { return ((size_t)(n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
 
 enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4, HDR_WORDS = 16 };
 enum { STATUS_BAD_INDEX = 1, STATUS_ETA_ROWS = 2, STATUS_CHOL_FAIL = 4 };
@@ -18,7 +23,7 @@ enum { STATUS_BAD_INDEX = 1, STATUS_ETA_ROWS = 2, STATUS_CHOL_FAIL = 4 };
 struct BaView {
   int E, nbuf, H, W, HW;
   int t0, t1, P, M;        // window, poses in it, depth slots the host sized the buffers for
-  int n, ld;               // n = 6P unknowns; system is (n+1) x ld, ld = roundup8(n+1), row n = rhs
+  int n, ld;               // n = 6P unknowns; system is (n+1) x ld, ld = roundup16(n+1) (128-byte rows), row n = rhs
   int nch;                 // pixel chunks of the linearisation kernel
   int own0, own1;          // frames whose depth this rank owns
   int motion_only;         // prep: validate indices only, no depth slots
@@ -45,7 +50,8 @@ struct BaView {
   double* sys;             // [n+1][ld] reduced camera system, lower triangle, row n = rhs
   double* xsol;            // [ld] solve scratch / solution
   float* dx;               // [P][6]
-  int* bs_flags;           // [ceil(n/64)] hand-off flags of the backward substitution
+  int* bs_flags;           // [chol_flag_words(n)] hand-off flags of the single-launch factorisation
+  double* ldiag;           // [ceil(n/64)][64][64] factored diagonal tiles of the single-launch factorisation
 };
 
 struct BaSizes {
@@ -56,7 +62,7 @@ struct BaSizes {
 inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t0, int t1, int M) {
   v.E = E; v.nbuf = nbuf; v.H = H; v.W = W; v.HW = H * W;
   v.t0 = t0; v.t1 = t1; v.P = t1 - t0; v.M = M;
-  v.n = 6 * v.P; v.ld = (v.n + 1 + 7) & ~7;
+  v.n = 6 * v.P; v.ld = chol_ld(v.n);
   v.nch = (v.HW + LIN_CP - 1) / LIN_CP;
   v.own0 = 0; v.own1 = nbuf; v.motion_only = 0;
   size_t off = 0;
@@ -95,8 +101,9 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   if (v.zsplit > 1) v.zpart = static_cast<float*>(take(sizeof(float) * ((size_t)v.zsplit * M * 8 * v.HW + 64)));
   v.sys = static_cast<double*>(take(sizeof(double) * ((size_t)(v.n + 1) * v.ld + 8)));
   v.xsol = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld + 1)));
+  v.bs_flags = static_cast<int*>(take(sizeof(int) * chol_flag_words(v.n)));   // directly after xsol: one fill presets both
+  v.ldiag = static_cast<double*>(take(sizeof(double) * chol_ldiag_doubles(v.n)));
   v.dx = static_cast<float*>(take(sizeof(float) * ((size_t)v.n + 8)));
-  v.bs_flags = static_cast<int*>(take(sizeof(int) * ((size_t)v.n / CHOL_NB + 2)));
   return off;
 }
 
@@ -113,13 +120,16 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
 void launch_update(const BaView& v, float* poses, float* disps, const float* intr, const float* weights,
                    const int64_t* ii, const int64_t* jj, const double* x, float* dx_out, float* dz_out,
                    bool motion_only, hipStream_t s);
-// In-place damped Cholesky of the lower triangle of sys (ld x ld, row n = rhs) + solve -> x [n].
-// flags: >= ceil(n/64) ints of scratch for the single-launch backward substitution (may be null)
+// In-place damped Cholesky of the lower triangle of sys ((n+1) x ld, row n = rhs) + solve -> x [n].
+// flags [chol_flag_words(n)] and ldiag [chol_ldiag_doubles(n)]: scratch of the single-launch factorisation
+// (null: one launch per block column).  launch_chol_solve presets x and flags itself; callers of the two
+// halves preset them with 0xFF bytes before launch_chol_factor.
 void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
-                       int* flags, hipStream_t s);
+                       int* flags, double* ldiag, hipStream_t s);
 
-void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag,
-                        hipStream_t s);
-void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, int* err, hipStream_t s);
+void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag, int* flags,
+                        double* ldiag, hipStream_t s);
+void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, double* ldiag, int* err,
+                           hipStream_t s);
 
 }  // namespace droid

@@ -20,6 +20,9 @@
 //   * update kernel: A22 -= L21 L21^T, one 64x64 tile per workgroup on v_mfma_f64_16x16x4.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+#include <cstdlib>
+
 #include "ba_internal.hpp"
 
 namespace droid {
@@ -27,16 +30,26 @@ namespace droid {
 constexpr int NB = CHOL_NB;
 
 #ifdef CHOL_STAMPS
-// Diagnostic build only: s_memtime stamps of wave 0 of the first two panel workgroups.
+// Diagnostic build only.  Per-step kernel: s_memtime stamps of wave 0 of the first two panel workgroups.
+// Single-launch kernel: wall-clock (100 MHz, chip-wide) stamps of the diagonal workgroup and the one below it;
+// slots 11..13 = {wait begins, inputs seen, tile published}.
 __device__ unsigned long long g_chol_stamps[64 * 16];
 #define STAMP(slot)                                                                         \
   do {                                                                                      \
-    if (threadIdx.x == 0 && panel && (blockIdx.x < 2)) {                                     \
+    if (!PERSIST && threadIdx.x == 0 && panel && (blockIdx.x < 2)) {                                     \
       g_chol_stamps[((k + 1) & 31) * 32 + blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
     }                                                                                       \
+    if (PERSIST && threadIdx.x == 0 && panel && (bi - kp < 2)) {                              \
+      g_chol_stamps[((k + 1) & 31) * 32 + (bi - kp) * 16 + (slot)] = wall_clock64();          \
+    }                                                                                       \
+  } while (0)
+#define PSTAMP(slot)                                                                        \
+  do {                                                                                      \
+    if (t == 0 && panel && (bi - kp < 2)) g_chol_stamps[(kp & 31) * 32 + (bi - kp) * 16 + (slot)] = wall_clock64(); \
   } while (0)
 #else
 #define STAMP(slot) do { } while (0)
+#define PSTAMP(slot) do { } while (0)
 #endif
 constexpr int LDP = NB + 2;  // LDS row pitch in doubles: rows stay 16-B aligned, b64 MFMA operand reads conflict-free
 
@@ -44,13 +57,37 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+// LDS-qualified pointers: every helper below takes its tiles through these, so non-inlined helpers
+// read them with ds_read instead of flat loads and no generic-pointer casts are generated
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) f64x2 lds_f64x2;
+#define DROID_LDS(arr) ((lds_f64*)(arr))
+// global-memory-qualified pointers for the same reason: inside a non-kernel function a plain double* is a
+// generic pointer and every access a flat instruction that also ties up the LDS counter
+typedef __attribute__((address_space(1))) double gbl_f64;
+typedef __attribute__((address_space(1))) f64x2 gbl_f64x2;
+// COH: data handed between workgroups of the single-launch factorisation while the kernel runs.  Agent-scope
+// relaxed atomics = sc1 loads/stores: written through to memory and re-fetched past the per-XCD L2s, so the
+// hand-off needs no L2 write-back / invalidate (an agent-scope release+acquire fence pair per tile cost more
+// than the kernel boundary it replaced).
+template <bool COH>
+__device__ __forceinline__ double gload(const gbl_f64* p) {
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void gstore(gbl_f64* p, double v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
 
 // Cooperative load of a 64x64 fp64 tile (rows r0.., cols c0..c0+63 of S) into LDS by 256 threads:
 // 8 independent 16-byte loads per thread are issued before the first LDS store, so the tile costs
 // one memory round trip instead of sixteen.  Rows >= row_end and columns >= col_end read as
 // `fill_diag` on the (tile-local) diagonal and 0 elsewhere; with `lower` only j <= i is kept.
 // Requires ld % 2 == 0 and c0 % 2 == 0 (16-byte aligned rows).
-__device__ __forceinline__ void load_tile64(double* __restrict__ dst, const double* __restrict__ S,
+template <bool COH = false>
+__device__ __forceinline__ void load_tile64(lds_f64* __restrict__ dst, const gbl_f64* __restrict__ S,
                                             int ld, int r0, int c0, int row_begin, int row_end,
                                             int col_end, bool lower, double fill_diag) {
   const int t = threadIdx.x & 255;  // a 256-thread group (workgroups of 512 threads run two)
@@ -60,9 +97,20 @@ __device__ __forceinline__ void load_tile64(double* __restrict__ dst, const doub
     const int idx2 = it * 256 + t;
     const int i = idx2 >> 5, j = (idx2 & 31) * 2;
     const bool ok = (r0 + i >= row_begin) && (r0 + i < row_end) && (c0 + j < col_end);
-    const double* p = S + (size_t)(ok ? r0 + i : 0) * ld + (ok ? c0 + j : 0);
-    v[it] = *reinterpret_cast<const f64x2*>(p);
-    if (!ok) v[it] = (f64x2){0.0, 0.0};
+    const gbl_f64* p = S + (size_t)(ok ? r0 + i : 0) * ld + (ok ? c0 + j : 0);
+    if (COH) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[it]) : "v"(p) : "memory");
+    else v[it] = *(const gbl_f64x2*)p;
+    if (!COH && !ok) v[it] = (f64x2){0.0, 0.0};
+  }
+  if (COH) {  // the compiler does not count loads issued from inline asm
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      asm volatile("" : "+v"(v[it]));
+      const int idx2 = it * 256 + t;
+      const int i = idx2 >> 5, j = (idx2 & 31) * 2;
+      if (!((r0 + i >= row_begin) && (r0 + i < row_end) && (c0 + j < col_end))) v[it] = (f64x2){0.0, 0.0};
+    }
   }
 #pragma unroll
   for (int it = 0; it < 8; it++) {
@@ -79,15 +127,30 @@ __device__ __forceinline__ void load_tile64(double* __restrict__ dst, const doub
       if (j == i && !(rok && c0 + j < col_end)) a = fill_diag;
       if (j + 1 == i && !(rok && c0 + j + 1 < col_end)) b = fill_diag;
     }
-    *reinterpret_cast<f64x2*>(&dst[i * LDP + j]) = (f64x2){a, b};
+    *(lds_f64x2*)(&dst[i * LDP + j]) = (f64x2){a, b};
   }
 }
 
 // Store rows [row_begin,row_end) x cols [0,ncols) of an LDS tile back (optionally lower part only).
-__device__ __forceinline__ void store_tile64(double* __restrict__ S, const double* __restrict__ src,
+template <bool COH = false>
+__device__ __forceinline__ void store_tile64(gbl_f64* __restrict__ S, const lds_f64* __restrict__ src,
                                              int ld, int r0, int c0, int row_begin, int row_end,
                                              int ncols, bool lower) {
   const int t = threadIdx.x & 255;
+  if (COH) {  // 16-byte write-through stores (8-byte ones take 2.5x as long per tile); never `lower`
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int idx2 = it * 256 + t;
+      const int i = idx2 >> 5, j = (idx2 & 31) * 2;
+      if (r0 + i >= row_begin && r0 + i < row_end && j < ncols) {
+        gbl_f64* p = &S[(size_t)(r0 + i) * ld + c0 + j];
+        const f64x2 v = *(const lds_f64x2*)&src[i * LDP + j];
+        if (j + 1 < ncols) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        else gstore<true>(p, v[0]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < 16; it++) {
     const int idx = it * 256 + t;
@@ -123,8 +186,15 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // twice per workgroup; inlined, every call site is cold code and the instruction-cache misses cost
 // 4-5x the arithmetic (measured with s_memtime: 2.3-3.1k cycles cold vs 0.5k warm per call).
 template <bool ASSIGN>
-__device__ __attribute__((noinline)) void wave_gemm_nt16(double* C, const double* A, const double* B, int ldb) {
+__device__ __attribute__((noinline)) void wave_gemm_nt16(lds_f64* Cl, const lds_f64* Al, const lds_f64* Bl, int ldb) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  // The operands are read with FLAT loads on purpose: measured on the pivot chain, the ds_read form of this
+  // function (whatever the order of reads and MFMAs) costs 1.3 us more per block column than eight flat loads
+  // issued back to back.  The pointers are laundered so that address-space inference does not turn them back.
+  double* C = (double*)Cl;
+  const double* A = (const double*)Al;
+  const double* B = (const double*)Bl;
+  asm volatile("" : "+v"(C), "+v"(A), "+v"(B));
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < 16; k += 4)
@@ -183,7 +253,7 @@ __device__ __forceinline__ void potrf16_pivot(double (&a)[16], double (&w)[16], 
   }
 }
 
-__device__ __forceinline__ void wave_potrf16(double* Lb, double* Wl, const double* Idn, int* fail, bool report) {
+__device__ __forceinline__ void wave_potrf16(lds_f64* Lb, lds_f64* Wl, const lds_f64* Idn, int* fail, bool report) {
   const int lane = threadIdx.x & 63, row = lane & 15;
   __builtin_amdgcn_s_setprio(3);  // the pivot chain outranks the MFMA waves sharing this SIMD
   double a[16], w[16];
@@ -213,11 +283,11 @@ __device__ __forceinline__ void wave_potrf16(double* Lb, double* Wl, const doubl
 
 // 16-row strip of a 64x64 tile update: acc[0..NN) (row group rg, column tiles nt0..nt0+NN) -= Lr Lc^T.
 template <int NN>
-__device__ __forceinline__ void strip_update(f64x4 (&acc)[4], const double* Lr, const double* Lc, int rg,
+__device__ __forceinline__ void strip_update(f64x4 (&acc)[4], const lds_f64* Lr, const lds_f64* Lc, int rg,
                                              int nt0) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
-  const double* Ar = &Lr[(16 * rg + r) * LDP + g];
+  const lds_f64* Ar = &Lr[(16 * rg + r) * LDP + g];
 #pragma unroll 4
   for (int kk = 0; kk < NB; kk += 4) {
     const double a = -Ar[kk];
@@ -229,7 +299,7 @@ __device__ __forceinline__ void strip_update(f64x4 (&acc)[4], const double* Lr, 
 
 // accumulator fragment <- global: element i of tile nn is (row 16*rg + (lane>>4) + 4i, col 16*(nt0+nn) + (lane&15))
 template <int NN>
-__device__ __forceinline__ void frag_load_global(f64x4 (&acc)[4], const double* __restrict__ S, int ld,
+__device__ __forceinline__ void frag_load_global(f64x4 (&acc)[4], const gbl_f64* __restrict__ S, int ld,
                                                  int r0, int q0, int rg, int nt0, int row_end, int col_end,
                                                  bool lower) {
   const int lane = threadIdx.x & 63;
@@ -247,17 +317,18 @@ __device__ __forceinline__ void frag_load_global(f64x4 (&acc)[4], const double* 
 }
 
 // single-tile variants: one 16x16 accumulator fragment (row group rg, column tile nt)
-__device__ __forceinline__ void strip_update_tile(f64x4& acc, const double* Lr, const double* Lc, int rg, int nt) {
+__device__ __forceinline__ void strip_update_tile(f64x4& acc, const lds_f64* Lr, const lds_f64* Lc, int rg, int nt) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
-  const double* Ar = &Lr[(16 * rg + r) * LDP + g];
-  const double* Br = &Lc[(16 * nt + r) * LDP + g];
+  const lds_f64* Ar = &Lr[(16 * rg + r) * LDP + g];
+  const lds_f64* Br = &Lc[(16 * nt + r) * LDP + g];
   // fully unrolled: all 32 operand reads of the tile are in flight before the first MFMA, so the
   // LDS latency is paid once per tile and the 16 MFMAs issue back to back
 #pragma unroll
   for (int kk = 0; kk < NB; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ar[kk], Br[kk], acc, 0, 0, 0);
 }
-__device__ __forceinline__ void frag_load_tile(f64x4& acc, const double* __restrict__ S, int ld, int r0, int q0,
+template <bool COH = false>
+__device__ __forceinline__ void frag_load_tile(f64x4& acc, const gbl_f64* __restrict__ S, int ld, int r0, int q0,
                                                int rg, int nt, int row_end, int col_end, bool lower) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
@@ -266,13 +337,13 @@ __device__ __forceinline__ void frag_load_tile(f64x4& acc, const double* __restr
     const int li = 16 * rg + g + 4 * i, lj = 16 * nt + r;
     const int row = r0 + li, col = q0 + lj;
     double v = 0.0;
-    if (row < row_end && col < col_end && (!lower || lj <= li)) v = S[(size_t)row * ld + col];
+    if (row < row_end && col < col_end && (!lower || lj <= li)) v = gload<COH>(&S[(size_t)row * ld + col]);
     acc[i] = v;
   }
 }
 
 // acc (16x16 fragment) -= A(16x16 LDS block) * B(16x16 LDS block)^T, both with row pitch LDP
-__device__ __forceinline__ void block_update16(f64x4& acc, const double* A, const double* B) {
+__device__ __forceinline__ void block_update16(f64x4& acc, const lds_f64* A, const lds_f64* B) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int kk = 0; kk < 16; kk += 4)
@@ -294,17 +365,31 @@ __device__ __forceinline__ void block_update16(f64x4& acc, const double* A, cons
 //     then wave 0 updates block (p+1,p+1) and factors it while the other waves apply the
 //     remaining rank-16 updates of the diagonal tile and finish column p+1 of the tile to solve
 //     (its rank-64 update was deferred to this slot, where the matrix pipe is otherwise idle).
-__global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, int n, int ld, int k,
-                                                        int* __restrict__ fail, double lm, double ep) {
-  __shared__ double B0[NB * LDP];   // L[bi,k]
-  __shared__ double B1[NB * LDP];   // L[bj,k]
-  __shared__ double B2[NB * LDP];   // the diagonal tile D -> L
-  __shared__ double BT[NB * LDP];   // the tile being solved (T -> X)
-  __shared__ double Wl[4 * 256];    // inverses of the four 16x16 diagonal blocks
-  __shared__ double Idn[256];       // 16x16 identity: initial rows of the lanes that build L^-T
+// LDS tiles of a factorisation workgroup (145 KB: one workgroup per CU).  Declared at namespace scope so
+// that the step body can be a real function of the single-launch kernel without passing LDS arrays
+// around as generic pointers.
+__shared__ double g_cholB0[NB * LDP];
+__shared__ double g_cholB1[NB * LDP];
+__shared__ double g_cholB2[NB * LDP];
+__shared__ double g_cholBT[NB * LDP];
+__shared__ double g_cholWl[4 * 256];
+__shared__ double g_cholIdn[256];
+
+// The body is shared by the one-launch-per-step kernel and the single-launch kernel below
+// (PERSIST: the workgroup is handed tile (bi, bj) of step k by its caller, the factored diagonal
+// tile goes to the side buffer Ldiag instead of overwriting the tile other workgroups still read).
+template <bool PERSIST>
+__device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld, int k, int bi, int bj,
+                                          int* __restrict__ fail, double lm, double ep,
+                                          gbl_f64* __restrict__ Ldiag) {
+  lds_f64* const B0 = DROID_LDS(g_cholB0);      // L[bi,k]          (workgroup-local tiles, see their declaration)
+  lds_f64* const B1 = DROID_LDS(g_cholB1);      // L[bj,k]
+  lds_f64* const B2 = DROID_LDS(g_cholB2);      // the diagonal tile D -> L
+  lds_f64* const BT = DROID_LDS(g_cholBT);      // the tile being solved (T -> X)
+  lds_f64* const Wl = DROID_LDS(g_cholWl);      // inverses of the four 16x16 diagonal blocks
+  lds_f64* const Idn = DROID_LDS(g_cholIdn);    // 16x16 identity: initial rows of the lanes that build L^-T
   const int nrows = n + 1;          // row n = right-hand side
   const int kp = k + 1;             // block column being finished
-  const int bi = kp + blockIdx.x, bj = kp + blockIdx.y;
   if (bj > bi) return;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int grp = wave >> 2, w4 = wave & 3;
@@ -321,8 +406,9 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
     if (k < 0) {
       // initial launch: the spare workgroups of block column 1 apply the damping diag += ep + lm*diag
       // (SparseBlock::solve, dk:1197) to the rows below the first block; block 0 is damped on load
+      // (single-launch kernel: done by the owners of the diagonal tiles before the first step)
       const int i = r0 + t;
-      if (bj == kp + 1 && t < NB && i >= NB && i < n) {
+      if (!PERSIST && bj == kp + 1 && t < NB && i >= NB && i < n) {
         const double d = S[(size_t)i * ld + i];
         S[(size_t)i * ld + i] = d + (ep + lm * d);
       }
@@ -330,8 +416,8 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
     }
     const int p0 = k * NB;
     frag_load_global<2>(acc, S, ld, r0, q0, w4, 2 * grp, nrows, n, bi == bj);
-    if (grp == 0) load_tile64(B0, S, ld, r0, p0, r0, nrows, p0 + NB, false, 0.0);
-    else if (bi != bj) load_tile64(B1, S, ld, q0, p0, q0, n, p0 + NB, false, 0.0);
+    if (grp == 0) load_tile64<PERSIST>(B0, S, ld, r0, p0, r0, nrows, p0 + NB, false, 0.0);
+    else if (bi != bj) load_tile64<PERSIST>(B1, S, ld, q0, p0, q0, n, p0 + NB, false, 0.0);
     __syncthreads();
     strip_update<2>(acc, B0, (bi == bj) ? B0 : B1, w4, 2 * grp);
 #pragma unroll
@@ -340,7 +426,7 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
       for (int i = 0; i < 4; i++) {
         const int li = 16 * w4 + fg + 4 * i, lj = 16 * (2 * grp + nn) + fr;
         const int row = r0 + li, col = q0 + lj;
-        if (row < nrows && col < n && (bi != bj || lj <= li)) S[(size_t)row * ld + col] = acc[nn][i];
+        if (row < nrows && col < n && (bi != bj || lj <= li)) gstore<PERSIST>(&S[(size_t)row * ld + col], acc[nn][i]);
       }
     return;
   }
@@ -381,7 +467,7 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
       if (code[i] & 0x10) {
         if (solve_rows) frag_load_tile(tacc[i], S, ld, r0, c0, rg, nt, nrows, n, diag);   // tile to solve
       } else {
-        frag_load_tile(tacc[i], S, ld, c0, c0, rg, nt, c0 + wk, c0 + wk, true);            // diagonal tile
+        frag_load_tile<PERSIST>(tacc[i], S, ld, c0, c0, rg, nt, c0 + wk, c0 + wk, true);   // diagonal tile
         if (k < 0 && rg == nt) {  // damping of block 0, applied to every workgroup's private copy
 #pragma unroll
           for (int e = 0; e < 4; e++)
@@ -394,8 +480,8 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
   for (int i = 0; i < 3; i++)
     if (i < ndef) frag_load_tile(dacc[i], S, ld, r0, c0, dg, (wave >= 5) ? i + 1 : wave, nrows, n, diag);
   if (k >= 0) {
-    if (grp == 0) load_tile64(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
-    else load_tile64(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
+    if (grp == 0) load_tile64<PERSIST>(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
+    else load_tile64<PERSIST>(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
   }
   __syncthreads();
   STAMP(1);
@@ -497,11 +583,151 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
   }
   STAMP(8);
   if (grp == 0) {
-    if (diag) store_tile64(S, B2, ld, c0, c0, c0, c0 + wk, wk, true);
+    if (diag) {
+      if (PERSIST) store_tile64(Ldiag + (size_t)kp * NB * NB, B2, NB, 0, 0, 0, NB, NB, true);
+      else store_tile64(S, B2, ld, c0, c0, c0, c0 + wk, wk, true);
+    }
   } else if (solve_rows) {
-    store_tile64(S, BT, ld, r0, c0, max(r0, c0 + wk), min(r0 + NB, nrows), wk, false);
+    store_tile64<PERSIST>(S, BT, ld, r0, c0, max(r0, c0 + wk), min(r0 + NB, nrows), wk, false);
   }
   STAMP(9);
+}
+
+__global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, int n, int ld, int k,
+                                                        int* __restrict__ fail, double lm, double ep) {
+  chol_tile<false>((gbl_f64*)S, n, ld, k, k + 1 + (int)blockIdx.x, k + 1 + (int)blockIdx.y, fail, lm, ep, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The whole factorisation in ONE launch.  A kernel boundary per block column costs 3-4.5 us of
+// the 17 us step and makes the pivot chain wait for the slowest trailing tile; here a grid of
+// co-resident workgroups (one per CU: 145 KB of LDS) walks the steps itself.
+//   * static ownership: lower-triangle tiles in column-major order, tile idx -> workgroup
+//     idx % grid; a workgroup applies every step to its own tiles, so a tile's intermediate
+//     versions never change hands (and panel tiles come first in every workgroup's step);
+//   * data flow instead of barriers: done[i] = last final tile L[i, c] of block row i,
+//     dver[j] = trailing updates applied to the diagonal tile (j, j) by its owner (0 = damped).
+//     Tile (bi, bj) at step k waits for done[bi] >= k and done[bj] >= k, a panel tile also for
+//     dver[k+1] >= k; nothing waits for unrelated trailing tiles (look-ahead comes for free);
+//   * hand-off without cache maintenance: every tile store is written through (sc1), tiles of other
+//     workgroups are read with sc1 loads, the flags likewise: store, s_waitcnt vmcnt(0), barrier, flag |
+//     flag poll, barrier, loads.  Rows are 128-byte aligned (ld % 16 == 0) so tiles of different
+//     workgroups never share a cache line of the per-XCD L2s;
+//   * the factored diagonal tile L_jj goes to Ldiag[j] (64x64): the other panel workgroups of the
+//     column read the unfactored tile at their own pace;
+//   * every spin is bounded: a stalled grid raises `abort`, reports a failed factorisation and
+//     drains (it cannot happen with a resident grid; the GPU is never left hanging).
+constexpr int CFP_SPIN_LIMIT = 1 << 20;
+
+__device__ __forceinline__ int cfp_load(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cfp_store(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One tile of one step.  NOT inlined into the step loops: inlined, the loop-invariant lane offsets of the
+// whole body are hoisted in front of the loops and held (or spilled) across them.
+__device__ __attribute__((noinline)) void chol_tile_persist(double* __restrict__ S, int n, int ld, int k, int bi,
+                                                            int bj, int* __restrict__ fail, double lm, double ep,
+                                                            double* __restrict__ Ldiag) {
+  chol_tile<true>((gbl_f64*)S, n, ld, k, bi, bj, fail, lm, ep, (gbl_f64*)Ldiag);
+}
+
+__global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __restrict__ S, int n, int ld,
+                                                                     int* __restrict__ fail, double lm, double ep,
+                                                                     int* __restrict__ flags,
+                                                                     double* __restrict__ Ldiag) {
+  __shared__ int s_abort;
+  const int nb = (n + NB - 1) / NB;       // block columns
+  const int nrb = (n + 1 + NB - 1) / NB;  // block rows (row n = rhs)
+  int* done = flags;
+  int* dver = flags + nrb;
+  int* abortf = flags + 2 * nrb;
+  const int G = (int)gridDim.x, wg = (int)blockIdx.x, t = (int)threadIdx.x;
+  int total = 0;
+  for (int j = 0; j < nb; j++) total += nrb - j;
+
+  {  // damping diag += ep + lm*diag (dk:1197) of the blocks >= 1 by the owners of their diagonal tiles
+    int cs = 0;
+    for (int j = 0; j < nb; j++) {
+      if (j >= 1 && (cs % G) == wg) {
+        const int i = j * NB + t;
+        if (t < NB && i < n) {
+          const double d = S[(size_t)i * ld + i];
+          gstore<true>((gbl_f64*)&S[(size_t)i * ld + i], d + (ep + lm * d));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have been acknowledged
+        __syncthreads();
+        if (t == 0) cfp_store(&dver[j], 0);
+      }
+      cs += nrb - j;
+    }
+  }
+
+  int colstart = 0;  // index of tile (kp, kp)
+#pragma unroll 1
+  for (int k = -1; k + 1 < nb; k++) {
+    const int kp = k + 1;
+    int idx = colstart + (((wg - colstart) % G) + G) % G;
+    int cj = kp, cs = colstart;
+#pragma unroll 1
+    for (; idx < total; idx += G) {
+      while (idx >= cs + (nrb - cj)) {
+        cs += nrb - cj;
+        cj++;
+      }
+      const int bj = __builtin_amdgcn_readfirstlane(cj), bi = __builtin_amdgcn_readfirstlane(cj + (idx - cs));
+      if (k < 0 && bj != 0) break;  // step -1 is the first panel only
+      const bool panel = (bj == kp);
+      // ---- wait for the inputs (wave 0: one flag per lane)
+      PSTAMP(11);
+      if (t < 64) {
+        bool ok = true;
+        if (k >= 0) {
+          const int* p = nullptr;
+          if (t == 0) p = &done[bi];
+          else if (t == 1 && bj != bi) p = &done[bj];
+          else if (t == 2 && panel && bi != bj) p = &dver[bj];
+          bool sat = (p == nullptr);
+          int spins = 0;
+          while (true) {
+            if (!sat) sat = cfp_load(p) >= k;
+            if (__all(sat)) break;
+            spins++;
+            if (spins > CFP_SPIN_LIMIT || ((spins & 255) == 0 && __any(cfp_load(abortf) == 1))) {
+              ok = false;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        } else if (__any(cfp_load(abortf) == 1)) {
+          ok = false;
+        }
+        if (t == 0) {
+          s_abort = ok ? 0 : 1;
+          if (!ok) {
+            cfp_store(abortf, 1);
+            atomicExch(fail, 1);
+          }
+        }
+      }
+      PSTAMP(12);
+      __syncthreads();  // also: the previous tile's LDS reads are over
+      if (s_abort) return;
+      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag);
+      if (panel || bi == bj) {  // publish: final tile of row bi, or the next version of a diagonal tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's write-through stores are acknowledged
+        __syncthreads();
+        if (t == 0) {
+          if (panel) cfp_store(&done[bi], kp);
+          else cfp_store(&dver[bj], k + 1);
+        }
+        PSTAMP(13);
+      }
+    }
+    colstart += nrb - kp;
+  }
 }
 
 // One block column of the backward substitution L^T x = y (y = row n of S, consumed in place):
@@ -513,7 +739,7 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(double* __restrict_
   const int t = threadIdx.x;
   const int c0 = k * NB;
   const int wk = min(NB, n - c0);
-  load_tile64(L, S, ld, c0, c0, c0, c0 + wk, c0 + wk, true, 1.0);
+  load_tile64(DROID_LDS(L), (const gbl_f64*)S, ld, c0, c0, c0, c0 + wk, c0 + wk, true, 1.0);
   __syncthreads();
   if (t < 64) {
     // lane j owns z_j; column-oriented back substitution with static lane broadcasts
@@ -561,7 +787,7 @@ constexpr int BSP_MAX_BLOCKS = 200;
 constexpr long long BSP_SENTINEL = -1LL;
 
 // 64x64 tile -> LDS by the 192 threads of waves 1..3 (11 independent 16-byte loads per thread)
-__device__ __forceinline__ void load_tile64_w123(double* __restrict__ dst, const double* __restrict__ S,
+__device__ __forceinline__ void load_tile64_w123(lds_f64* __restrict__ dst, const gbl_f64* __restrict__ S,
                                                  int ld, int r0, int c0, int row_end, int col_end) {
   const int t = threadIdx.x - 64;
   f64x2 v[11];
@@ -570,8 +796,8 @@ __device__ __forceinline__ void load_tile64_w123(double* __restrict__ dst, const
     const int idx2 = it * 192 + t;
     const int i = idx2 >> 5, j = (idx2 & 31) * 2;
     const bool ok = (idx2 < 2048) && (r0 + i < row_end) && (c0 + j < col_end);
-    const double* p = S + (size_t)(ok ? r0 + i : 0) * ld + (ok ? c0 + j : 0);
-    v[it] = *reinterpret_cast<const f64x2*>(p);
+    const gbl_f64* p = S + (size_t)(ok ? r0 + i : 0) * ld + (ok ? c0 + j : 0);
+    v[it] = *(const gbl_f64x2*)p;
     if (!ok) v[it] = (f64x2){0.0, 0.0};
     else if (c0 + j + 1 >= col_end) v[it][1] = 0.0;
   }
@@ -580,13 +806,14 @@ __device__ __forceinline__ void load_tile64_w123(double* __restrict__ dst, const
     const int idx2 = it * 192 + t;
     if (idx2 < 2048) {
       const int i = idx2 >> 5, j = (idx2 & 31) * 2;
-      *reinterpret_cast<f64x2*>(&dst[i * LDP + j]) = v[it];
+      *(lds_f64x2*)(&dst[i * LDP + j]) = v[it];
     }
   }
 }
 
 __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
-    double* __restrict__ S, int n, int ld, double* __restrict__ x, int* __restrict__ err) {
+    double* __restrict__ S, int n, int ld, double* __restrict__ x, int* __restrict__ err,
+    const double* __restrict__ Ldiag) {
   __shared__ double Ld[NB * LDP];
   __shared__ double Tt[2][NB * LDP];
   __shared__ double xk[NB];
@@ -597,10 +824,11 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
   const int c0 = j * NB;
   const int wj = min(NB, n - c0);
   if (t == 0) dead = 0;
-  load_tile64(Ld, S, ld, c0, c0, c0, c0 + wj, c0 + wj, true, 1.0);
+  if (Ldiag) load_tile64(DROID_LDS(Ld), (const gbl_f64*)Ldiag + (size_t)j * NB * NB, NB, 0, 0, 0, wj, wj, true, 1.0);  // single-launch factor
+  else load_tile64(DROID_LDS(Ld), (const gbl_f64*)S, ld, c0, c0, c0, c0 + wj, c0 + wj, true, 1.0);
   double z = (t < wj) ? S[(size_t)n * ld + c0 + t] : 0.0;  // wave 0 owns z
   int cur = 0;
-  if (j < nb - 1 && t >= 64) load_tile64_w123(Tt[0], S, ld, (nb - 1) * NB, c0, n, c0 + wj);
+  if (j < nb - 1 && t >= 64) load_tile64_w123(DROID_LDS(Tt[0]), (const gbl_f64*)S, ld, (nb - 1) * NB, c0, n, c0 + wj);
   __syncthreads();
   double Lcol[NB];  // wave 0: column t of the diagonal tile (rows above the diagonal read 0)
   if (t < 64) {
@@ -609,7 +837,7 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
   }
   for (int k = nb - 1; k > j; k--) {
     if (t >= 64) {
-      if (k - 1 > j) load_tile64_w123(Tt[cur ^ 1], S, ld, (k - 1) * NB, c0, n, c0 + wj);
+      if (k - 1 > j) load_tile64_w123(DROID_LDS(Tt[cur ^ 1]), (const gbl_f64*)S, ld, (k - 1) * NB, c0, n, c0 + wj);
     } else {
       // poll this lane's element of x_k (lanes beyond the matrix take 0)
       const int gi = k * NB + t;
@@ -683,23 +911,54 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
   }
 }
 
-void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag,
-                        hipStream_t s) {
+// Single-launch path: needs the hand-off flags, the side buffer for the factored diagonal tiles,
+// 128-byte aligned rows (no cache line shared between tiles of different workgroups) and a grid
+// that is resident as a whole.
+static int chol_resident_workgroups() {
+  static int cached = -1;
+  if (cached < 0) {
+    int dev = 0, occ = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, chol_factor_persistent_kernel, 512, 0) != hipSuccess)
+      cached = 0;
+    else
+      cached = occ * prop.multiProcessorCount;
+  }
+  return cached;
+}
+
+static bool chol_single_launch(const double* sys, int n, int ld, const int* flags, const double* ldiag) {
+  static const bool off = (getenv("DROID_CHOL_MULTI_LAUNCH") != nullptr);  // diagnostics: the per-step path
+  const int nb = (n + NB - 1) / NB;
+  return !off && flags != nullptr && ldiag != nullptr && nb >= 2 && (ld % 16) == 0 &&
+         (reinterpret_cast<uintptr_t>(sys) % 128) == 0 && chol_resident_workgroups() >= 8;
+}
+
+void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag, int* flags,
+                        double* ldiag, hipStream_t s) {
   if (n <= 0) return;
   const int nb = (n + NB - 1) / NB;        // block columns
   const int nrb = (n + 1 + NB - 1) / NB;   // block rows (row n = rhs)
+  if (chol_single_launch(sys, n, ld, flags, ldiag)) {
+    int total = 0;
+    for (int j = 0; j < nb; j++) total += nrb - j;
+    const int grid = total < chol_resident_workgroups() ? total : chol_resident_workgroups();
+    hipLaunchKernelGGL(chol_factor_persistent_kernel, dim3(grid), dim3(512), 0, s, sys, n, ld, fail_flag, lm,
+                       ep, flags, ldiag);
+    return;
+  }
   for (int k = -1; k + 1 < nb; k++)         // launch k finishes panel k+1; launch -1 also damps
     hipLaunchKernelGGL(chol_step_kernel, dim3(nrb - k - 1, k < 0 ? 2 : nb - k - 1), dim3(512), 0, s, sys, n,
                        ld, k, fail_flag, lm, ep);
 }
 
-void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, int* err,
+void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, double* ldiag, int* err,
                            hipStream_t s) {
   const int nb = (n + NB - 1) / NB;
   if (flags != nullptr && nb >= 2 && nb <= BSP_MAX_BLOCKS) {
-    (void)flags;
-    (void)hipMemsetAsync(x, 0xFF, sizeof(double) * n, s);  // sentinel = "not yet published"
-    hipLaunchKernelGGL(chol_backsolve_persistent_kernel, dim3(nb), dim3(256), 0, s, sys, n, ld, x, err);
+    hipLaunchKernelGGL(chol_backsolve_persistent_kernel, dim3(nb), dim3(256), 0, s, sys, n, ld, x, err,
+                       chol_single_launch(sys, n, ld, flags, ldiag) ? ldiag : nullptr);
     return;
   }
   for (int k = nb - 1; k >= 0; k--) {
@@ -709,11 +968,22 @@ void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, in
   }
 }
 
+// x [n] and flags [chol_flag_words(n)] are pre-set to 0xFF bytes here ("nothing published yet"); when the
+// flags directly follow x (BA workspace) one fill covers both.
 void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
-                       int* flags, hipStream_t s) {
+                       int* flags, double* ldiag, hipStream_t s) {
   if (n <= 0) return;
-  launch_chol_factor(sys, n, ld, lm, ep, fail_flag, s);
-  launch_chol_backsolve(sys, n, ld, x, flags, fail_flag, s);
+  const size_t xbytes = sizeof(double) * (size_t)n, fbytes = flags ? sizeof(int) * chol_flag_words(n) : 0;
+  char* xb = reinterpret_cast<char*>(x);
+  char* fb = reinterpret_cast<char*>(flags);
+  if (flags && fb >= xb + xbytes && fb - xb <= (ptrdiff_t)(xbytes + 4096)) {
+    (void)hipMemsetAsync(x, 0xFF, (size_t)(fb - xb) + fbytes, s);
+  } else {
+    (void)hipMemsetAsync(x, 0xFF, xbytes, s);
+    if (flags) (void)hipMemsetAsync(flags, 0xFF, fbytes, s);
+  }
+  launch_chol_factor(sys, n, ld, lm, ep, fail_flag, flags, ldiag, s);
+  launch_chol_backsolve(sys, n, ld, x, flags, ldiag, fail_flag, s);
 }
 
 #ifdef CHOL_STAMPS

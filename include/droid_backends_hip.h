@@ -151,7 +151,8 @@ int droid_ba_status(const void *workspace, void *stream, int *status_out, int *d
 
 /* Dense SPD solve used by the BA (exposed for tests): A [n,n] fp64 row-major (lower triangle
  * read, destroyed), b [n] fp64 -> x [n] fp64.  fail_flag (device int) is set to 1 when a pivot
- * is not positive.  scratch: >= (n+1)*(n+8) + n/64 + 8 doubles. */
+ * is not positive.  scratch (128-byte aligned): >= (n+1)*(n+16) + 4096*(n/64+1) + n/64 + 16 doubles
+ * (the augmented system with 128-byte rows, the factored 64x64 diagonal tiles, hand-off flags). */
 int droid_chol_solve(const double *A, const double *b, double *x, int n, double *scratch,
                      int *fail_flag, void *stream);
 

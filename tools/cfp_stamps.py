@@ -1,3 +1,5 @@
+"""Wall-clock stamps (10 ns ticks) of the single-launch Cholesky: diagonal workgroup (0) and the one below (1).
+Build: -DCHOL_STAMPS into tools/libs/lib_stamps.so (tools/README.md)."""
 import sys, ctypes
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/droid-slam_reserch_amd")
 import numpy as np, torch
@@ -18,9 +20,10 @@ print("err", np.abs(x.cpu().numpy() - np.linalg.solve(A, b)).max())
 buf = (ctypes.c_ulonglong * (64 * 16))()
 lib.droid_debug_chol_stamps(buf)
 st = np.array(buf[:], dtype=np.int64).reshape(32, 2, 16)
-labels = ["load", "updates+store", "potrf0", "barrier", "trsm0", "D11+potrf1", "trail0 barrier", "p=1..3", "store"]
-for kk in (1, 5, 12, 20):
+t0 = st[0, 0, 11]
+print("columns: wait-begin, inputs-seen, body-start(0), loaded(1), upd(2), potrf0(3), bar(4), trsm0(5), potrf1(6), (7), p123(8), stored(9), published(13); us since start")
+for kp in range(0, 24):
     for wg in (0, 1):
-        d = np.diff(st[kk, wg, :10])
-        print("   trsm0 gemm of wave 0 alone:", st[kk, wg, 10] - st[kk, wg, 4], "repeat1", st[kk, wg, 11] - st[kk, wg, 10], "repeat2", st[kk, wg, 12] - st[kk, wg, 11])
-        print(f"panel {kk} wg {wg} ({'diag' if wg == 0 else 'below'}):", " ".join(f"{nm}={v}" for nm, v in zip(labels, d)), "total", st[kk, wg, 9] - st[kk, wg, 0])
+        r = st[kp, wg]
+        seq = [r[11], r[12], r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[13]]
+        print(f"col {kp:2d} wg {wg}: " + " ".join(f"{(v - t0) / 100:7.2f}" for v in seq))
