@@ -198,8 +198,11 @@ int droid_ba_solve_update(float* poses, float* disps, const float* intrinsics, c
   if (!motion_only && (!intrinsics || (E > 0 && (!weights || !ii || !jj))))
     return fail(DROID_E_ARG, "ba: null %s", "intrinsics/weights/edges");
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
-  launch_chol_solve(v.sys, v.n, v.ld, (double)lm, (double)ep, v.xsol, v.hdr + HDR_CHOL_FAIL, v.bs_flags, v.ldiag, s);
+  // with edges, droid_ba_build's assemble kernel has preset the solver scratch and cleared the failure flag
+  const bool preset = E > 0;
+  if (!preset) (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
+  launch_chol_solve(v.sys, v.n, v.ld, (double)lm, (double)ep, v.xsol, v.hdr + HDR_CHOL_FAIL, v.bs_flags, v.ldiag, s,
+                    preset);
   launch_update(v, poses, disps, intrinsics, weights, ii, jj, v.xsol, dx_out, dz_out, motion_only != 0, s);
   return check_hip("ba_solve_update");
 }
@@ -248,8 +251,8 @@ int droid_ba_profile_iteration(float* poses, float* disps, const float* intrinsi
   (void)hipEventRecord(ev[3], s);
   launch_build_stage(v, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, motion_only != 0, 3, s);
   (void)hipEventRecord(ev[4], s);
-  (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
-  if (v.n > 0) {  // presets of x and the hand-off flags, as launch_chol_solve does
+  if (E <= 0) (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
+  if (v.n > 0 && E <= 0) {  // presets of x and the hand-off flags (with edges the assemble kernel did it)
     (void)hipMemsetAsync(v.xsol, 0xFF, sizeof(double) * (size_t)v.n, s);
     (void)hipMemsetAsync(v.bs_flags, 0xFF, sizeof(int) * chol_flag_words(v.n), s);
   }

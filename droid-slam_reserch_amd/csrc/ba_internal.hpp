@@ -11,10 +11,10 @@ constexpr int LIN_PPT = 2;                       // pixels per thread per chunk
 constexpr int LIN_CP = LIN_THREADS * LIN_PPT;    // pixels per workgroup chunk
 constexpr int CHOL_NB = 64;                      // Cholesky block size
 // row pitch of the augmented system in doubles: 128-byte rows, so 64-column tiles never share a cache line
-inline int chol_ld(int n) { return (n + 1 + 15) & ~15; }
+__host__ __device__ inline int chol_ld(int n) { return (n + 1 + 15) & ~15; }
 // ints of hand-off flags (done[], dver[], abort) and doubles of factored diagonal tiles for an n x n solve
-inline size_t chol_flag_words(int n) { return 2 * ((size_t)(n + 1 + CHOL_NB - 1) / CHOL_NB) + 8; }
-inline size_t chol_ldiag_doubles(int n) { return ((size_t)(n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
+__host__ __device__ inline size_t chol_flag_words(int n) { return 2 * ((size_t)(n + 1 + CHOL_NB - 1) / CHOL_NB) + 8; }
+__host__ __device__ inline size_t chol_ldiag_doubles(int n) { return ((size_t)(n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
 
 enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4, HDR_WORDS = 16 };
 enum { STATUS_BAD_INDEX = 1, STATUS_ETA_ROWS = 2, STATUS_CHOL_FAIL = 4 };
@@ -107,6 +107,14 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   return off;
 }
 
+// 4-byte words from xsol through the end of bs_flags (contiguous in the workspace): what one iteration's solve
+// expects preset to 0xFF bytes.  With edges, the assemble kernel's spare workgroups do it (and zero the failure
+// flag); without, droid_ba_solve_update falls back to fills.
+__host__ __device__ inline int solver_preset_words(const BaView& v) {
+  return (int)((reinterpret_cast<const char*>(v.bs_flags) - reinterpret_cast<const char*>(v.xsol)) / 4 +
+               (long)chol_flag_words(v.n));
+}
+
 // kernels' launchers (ba_kernels.hip / chol.hip)
 void launch_prep(const BaView& v, const int64_t* ii, const int64_t* jj, hipStream_t s);
 void launch_build(const BaView& v, const float* poses, const float* disps, const float* intr,
@@ -122,10 +130,10 @@ void launch_update(const BaView& v, float* poses, float* disps, const float* int
                    bool motion_only, hipStream_t s);
 // In-place damped Cholesky of the lower triangle of sys ((n+1) x ld, row n = rhs) + solve -> x [n].
 // flags [chol_flag_words(n)] and ldiag [chol_ldiag_doubles(n)]: scratch of the single-launch factorisation
-// (null: one launch per block column).  launch_chol_solve presets x and flags itself; callers of the two
-// halves preset them with 0xFF bytes before launch_chol_factor.
+// (null: one launch per block column).  launch_chol_solve presets x and flags itself unless told that it has
+// been done; callers of the two halves preset them with 0xFF bytes before launch_chol_factor.
 void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
-                       int* flags, double* ldiag, hipStream_t s);
+                       int* flags, double* ldiag, hipStream_t s, bool preset_done = false);
 
 void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag, int* flags,
                         double* ldiag, hipStream_t s);

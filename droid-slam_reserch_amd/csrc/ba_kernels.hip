@@ -563,6 +563,15 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaView v, const float* 
                                                           const int64_t* __restrict__ jj) {
   __shared__ double hj[6][6], vj[6], A[6][6], hij[6][6];
   const int e = blockIdx.x, t = threadIdx.x;
+  if (e >= v.E) {
+    // spare workgroups preset the solver's scratch for this iteration (saves two fill launches in front of the
+    // factorisation): solution vector and hand-off flags to 0xFF bytes, the failure flag to 0
+    unsigned* w = reinterpret_cast<unsigned*>(v.xsol);
+    const int words = solver_preset_words(v);
+    for (int i = (e - v.E) * 1024 + t; i < min(words, (e - v.E + 1) * 1024); i += 64) w[i] = 0xFFFFFFFFu;
+    if (e == v.E && t == 0) v.hdr[HDR_CHOL_FAIL] = 0;
+    return;
+  }
   const int64_t i64 = ii[e], j64 = jj[e];
   if (i64 < 0 || i64 >= v.nbuf || j64 < 0 || j64 >= v.nbuf) return;
   const int ix = (int)i64, jx = (int)j64;
@@ -1259,7 +1268,7 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
       break;
     case 1:
       if (v.E > 0)
-        hipLaunchKernelGGL(ba_assemble_kernel, dim3(v.E), dim3(64), 0, s, v, poses, ii, jj);
+        hipLaunchKernelGGL(ba_assemble_kernel, dim3(v.E + (solver_preset_words(v) + 1023) / 1024), dim3(64), 0, s, v, poses, ii, jj);
       break;
     case 2:
       if (depth) {

@@ -971,8 +971,13 @@ void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, do
 // x [n] and flags [chol_flag_words(n)] are pre-set to 0xFF bytes here ("nothing published yet"); when the
 // flags directly follow x (BA workspace) one fill covers both.
 void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
-                       int* flags, double* ldiag, hipStream_t s) {
+                       int* flags, double* ldiag, hipStream_t s, bool preset_done) {
   if (n <= 0) return;
+  if (preset_done) {
+    launch_chol_factor(sys, n, ld, lm, ep, fail_flag, flags, ldiag, s);
+    launch_chol_backsolve(sys, n, ld, x, flags, ldiag, fail_flag, s);
+    return;
+  }
   const size_t xbytes = sizeof(double) * (size_t)n, fbytes = flags ? sizeof(int) * chol_flag_words(n) : 0;
   char* xb = reinterpret_cast<char*>(x);
   char* fb = reinterpret_cast<char*>(flags);
