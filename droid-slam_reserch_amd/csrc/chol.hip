@@ -582,9 +582,21 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
     if (p == 0) STAMP(7);
   }
   STAMP(8);
+  if (PERSIST && diag) {
+    // the inverses of the four 16x16 diagonal blocks ride along in the unused upper blocks (0,1) (0,2) (0,3)
+    // (1,2) of the side-buffer tile: the backward substitution solves each 16-unknown block with them as one
+    // mat-vec instead of sixteen dependent steps
+#pragma unroll
+    for (int e = t; e < 1024; e += 512) {
+      const int pb = e >> 8, j = (e >> 4) & 15, kk = e & 15;
+      const int br = pb == 3 ? 1 : 0, bc = pb == 3 ? 2 : pb + 1;
+      B2[(16 * br + j) * LDP + 16 * bc + kk] = Wl[e];
+    }
+    __syncthreads();
+  }
   if (grp == 0) {
     if (diag) {
-      if (PERSIST) store_tile64(Ldiag + (size_t)kp * NB * NB, B2, NB, 0, 0, 0, NB, NB, true);
+      if (PERSIST) store_tile64(Ldiag + (size_t)kp * NB * NB, B2, NB, 0, 0, 0, NB, NB, false);
       else store_tile64(S, B2, ld, c0, c0, c0, c0 + wk, wk, true);
     }
   } else if (solve_rows) {
@@ -784,6 +796,12 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(double* __restrict_
 // separate flag, fence or drain is needed; MI355X guide: data-tagged 8-byte granules).  The grid
 // is co-resident (<= BSP_MAX_BLOCKS workgroups, one per CU) and every spin is bounded.
 constexpr int BSP_MAX_BLOCKS = 200;
+#ifdef CHOL_STAMPS
+__device__ unsigned long long g_bs_stamps[64 * 8];
+#define BSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 64) g_bs_stamps[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define BSTAMP(slot) do { } while (0)
+#endif
 constexpr long long BSP_SENTINEL = -1LL;
 
 // 64x64 tile -> LDS by the 192 threads of waves 1..3 (11 independent 16-byte loads per thread)
@@ -811,6 +829,8 @@ __device__ __forceinline__ void load_tile64_w123(lds_f64* __restrict__ dst, cons
   }
 }
 
+// FAST: the factorisation ran as one launch and left L_jj plus the inverses of its 16x16 diagonal blocks in Ldiag.
+template <bool FAST>
 __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
     double* __restrict__ S, int n, int ld, double* __restrict__ x, int* __restrict__ err,
     const double* __restrict__ Ldiag) {
@@ -823,22 +843,38 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
   const int j = blockIdx.x;
   const int c0 = j * NB;
   const int wj = min(NB, n - c0);
+  BSTAMP(0);
   if (t == 0) dead = 0;
-  if (Ldiag) load_tile64(DROID_LDS(Ld), (const gbl_f64*)Ldiag + (size_t)j * NB * NB, NB, 0, 0, 0, wj, wj, true, 1.0);  // single-launch factor
+  if (FAST) load_tile64(DROID_LDS(Ld), (const gbl_f64*)Ldiag + (size_t)j * NB * NB, NB, 0, 0, 0, wj, wj, true, 1.0);
   else load_tile64(DROID_LDS(Ld), (const gbl_f64*)S, ld, c0, c0, c0, c0 + wj, c0 + wj, true, 1.0);
   double z = (t < wj) ? S[(size_t)n * ld + c0 + t] : 0.0;  // wave 0 owns z
   int cur = 0;
   if (j < nb - 1 && t >= 64) load_tile64_w123(DROID_LDS(Tt[0]), (const gbl_f64*)S, ld, (nb - 1) * NB, c0, n, c0 + wj);
   __syncthreads();
   double Lcol[NB];  // wave 0: column t of the diagonal tile (rows above the diagonal read 0)
+  double Wcol[16];  // single-launch factor: column (t & 15) of the inverse of this lane's 16x16 diagonal block
   if (t < 64) {
 #pragma unroll
-    for (int i = 0; i < NB; i++) Lcol[i] = Ld[i * LDP + t];
+    for (int i = FAST ? 16 : 0; i < NB; i++) Lcol[i] = Ld[i * LDP + t];  // FAST: only the updates of the rows above
+    if (FAST) {
+      const int pb = t >> 4, br = pb == 3 ? 1 : 0, bc = pb == 3 ? 2 : pb + 1;
+      const double* Wg = Ldiag + (size_t)j * NB * NB + (size_t)(16 * br) * NB + 16 * bc + (t & 15);
+#pragma unroll
+      for (int c = 0; c < 16; c++) Wcol[c] = Wg[c * NB];  // (L_pp^-1)[c][t & 15]
+    }
   }
   for (int k = nb - 1; k > j; k--) {
     if (t >= 64) {
       if (k - 1 > j) load_tile64_w123(DROID_LDS(Tt[cur ^ 1]), (const gbl_f64*)S, ld, (k - 1) * NB, c0, n, c0 + wj);
     } else {
+      // column t of the tile (it landed before the last barrier) goes to registers BEFORE the poll: once x_k is
+      // there, the mat-vec is 32 broadcast reads and 64 FMAs (it was a rolled loop paying the LDS latency 16 times)
+      double Tc[NB];
+      {
+        const double* T = Tt[cur];
+#pragma unroll
+        for (int r = 0; r < NB; r++) Tc[r] = T[r * LDP + t];
+      }
       // poll this lane's element of x_k (lanes beyond the matrix take 0)
       const int gi = k * NB + t;
       double xv = 0.0;
@@ -856,22 +892,25 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
           __builtin_amdgcn_s_sleep(1);
         }
       }
+      if (k == j + 1) BSTAMP(1);
       xk[t] = xv;  // same wave writes and reads: LDS operations of one wave are ordered
-      const double* T = Tt[cur];
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 4
-      for (int r = 0; r < NB; r += 4) {
-        a0 = fma(T[(r + 0) * LDP + t], xk[r + 0], a0);
-        a1 = fma(T[(r + 1) * LDP + t], xk[r + 1], a1);
-        a2 = fma(T[(r + 2) * LDP + t], xk[r + 2], a2);
-        a3 = fma(T[(r + 3) * LDP + t], xk[r + 3], a3);
+#pragma unroll
+      for (int r = 0; r < NB; r += 4) {  // x_k in 16-byte broadcast reads against the preloaded column
+        const f64x2 x01 = *(const lds_f64x2*)&DROID_LDS(xk)[r], x23 = *(const lds_f64x2*)&DROID_LDS(xk)[r + 2];
+        a0 = fma(Tc[r + 0], x01[0], a0);
+        a1 = fma(Tc[r + 1], x01[1], a1);
+        a2 = fma(Tc[r + 2], x23[0], a2);
+        a3 = fma(Tc[r + 3], x23[1], a3);
       }
       z -= (a0 + a1) + (a2 + a3);
     }
     cur ^= 1;
+    if (k == j + 1) BSTAMP(2);
     __syncthreads();  // tile k-1 landed, tile k consumed
     if (dead) return;
   }
+  BSTAMP(3);
   if (t < 64) {
     // L_jj^T x = z by one wave, lane t = unknown t.  Measured: the plain 64-step lane-broadcast
     // loop cost 150 cycles per step (an LDS read of L[i][t] inside every dependent step).  Here
@@ -879,7 +918,7 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
     // solved inside its own 16-lane row with DPP broadcasts, and the rows above receive the block
     // through one 16-term update.
     double xsol = 0.0;
-    const double rinv = 1.0 / Ld[t * LDP + t];
+    const double rinv = FAST ? 0.0 : 1.0 / Ld[t * LDP + t];
     const int rr = t & 15, rowb = t >> 4;
 #define DROID_BS_STEP(B, II)                                                                            \
     {                                                                                                  \
@@ -889,25 +928,48 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
       z = fma(-Lcol[16 * B + II], xi, z);  /* zero for lanes above the diagonal; lane II itself is done */ \
       xsol = (rr == II) ? xi : xsol;                                                                   \
     }
+// with the block inverse: x_r = sum_c (L_pp^-1)[c][r] z_c, sixteen independent DPP-broadcast FMAs
+#define DROID_BS_WTERM(ACC, C)                                                                          \
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #C " row_mask:0xf bank_mask:0xf"             \
+                 : "+v"(ACC) : "v"(z), "v"(Wcol[C]));
 #define DROID_BS_BLOCK(B)                                                                               \
     if (rowb == B) {                                                                                   \
-      DROID_BS_STEP(B, 15) DROID_BS_STEP(B, 14) DROID_BS_STEP(B, 13) DROID_BS_STEP(B, 12)              \
-      DROID_BS_STEP(B, 11) DROID_BS_STEP(B, 10) DROID_BS_STEP(B, 9) DROID_BS_STEP(B, 8)                \
-      DROID_BS_STEP(B, 7) DROID_BS_STEP(B, 6) DROID_BS_STEP(B, 5) DROID_BS_STEP(B, 4)                  \
-      DROID_BS_STEP(B, 3) DROID_BS_STEP(B, 2) DROID_BS_STEP(B, 1) DROID_BS_STEP(B, 0)                  \
+      if (FAST) {                                                                                      \
+        double xw = 0.0, xv2 = 0.0;                                                                    \
+        asm volatile("s_nop 1" : "+v"(z));                                                             \
+        DROID_BS_WTERM(xw, 0) DROID_BS_WTERM(xv2, 1) DROID_BS_WTERM(xw, 2) DROID_BS_WTERM(xv2, 3)      \
+        DROID_BS_WTERM(xw, 4) DROID_BS_WTERM(xv2, 5) DROID_BS_WTERM(xw, 6) DROID_BS_WTERM(xv2, 7)      \
+        DROID_BS_WTERM(xw, 8) DROID_BS_WTERM(xv2, 9) DROID_BS_WTERM(xw, 10) DROID_BS_WTERM(xv2, 11)    \
+        DROID_BS_WTERM(xw, 12) DROID_BS_WTERM(xv2, 13) DROID_BS_WTERM(xw, 14) DROID_BS_WTERM(xv2, 15)  \
+        xsol = xw + xv2;                                                                               \
+      } else {                                                                                         \
+        DROID_BS_STEP(B, 15) DROID_BS_STEP(B, 14) DROID_BS_STEP(B, 13) DROID_BS_STEP(B, 12)            \
+        DROID_BS_STEP(B, 11) DROID_BS_STEP(B, 10) DROID_BS_STEP(B, 9) DROID_BS_STEP(B, 8)              \
+        DROID_BS_STEP(B, 7) DROID_BS_STEP(B, 6) DROID_BS_STEP(B, 5) DROID_BS_STEP(B, 4)                \
+        DROID_BS_STEP(B, 3) DROID_BS_STEP(B, 2) DROID_BS_STEP(B, 1) DROID_BS_STEP(B, 0)                \
+      }                                                                                                \
       xk[t] = xsol;                                                                                    \
     }                                                                                                  \
     if (B > 0 && rowb < B) {                                                                           \
-      _Pragma("unroll") for (int ii = 0; ii < 16; ii++) z = fma(-Lcol[16 * B + ii], xk[16 * B + ii], z); \
+      double u0 = 0.0, u1 = 0.0;                                                                       \
+      _Pragma("unroll") for (int ii = 0; ii < 16; ii += 2) {                                           \
+        const f64x2 xx = *(const lds_f64x2*)&DROID_LDS(xk)[16 * B + ii];                                \
+        u0 = fma(Lcol[16 * B + ii], xx[0], u0);                                                        \
+        u1 = fma(Lcol[16 * B + ii + 1], xx[1], u1);                                                    \
+      }                                                                                                \
+      z -= u0 + u1;                                                                                    \
     }
     DROID_BS_BLOCK(3)
     DROID_BS_BLOCK(2)
     DROID_BS_BLOCK(1)
     DROID_BS_BLOCK(0)
 #undef DROID_BS_BLOCK
+#undef DROID_BS_WTERM
 #undef DROID_BS_STEP
     if (__double_as_longlong(xsol) == BSP_SENTINEL) xsol = __longlong_as_double(0x7ff8000000000000LL);
+    BSTAMP(4);
     if (t < wj) __hip_atomic_store(&x[c0 + t], xsol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    BSTAMP(5);
   }
 }
 
@@ -957,8 +1019,11 @@ void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, do
                            hipStream_t s) {
   const int nb = (n + NB - 1) / NB;
   if (flags != nullptr && nb >= 2 && nb <= BSP_MAX_BLOCKS) {
-    hipLaunchKernelGGL(chol_backsolve_persistent_kernel, dim3(nb), dim3(256), 0, s, sys, n, ld, x, err,
-                       chol_single_launch(sys, n, ld, flags, ldiag) ? ldiag : nullptr);
+    if (chol_single_launch(sys, n, ld, flags, ldiag))
+      hipLaunchKernelGGL(chol_backsolve_persistent_kernel<true>, dim3(nb), dim3(256), 0, s, sys, n, ld, x, err, ldiag);
+    else
+      hipLaunchKernelGGL(chol_backsolve_persistent_kernel<false>, dim3(nb), dim3(256), 0, s, sys, n, ld, x, err,
+                         nullptr);
     return;
   }
   for (int k = nb - 1; k >= 0; k--) {
@@ -992,6 +1057,9 @@ void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double*
 }
 
 #ifdef CHOL_STAMPS
+extern "C" int droid_debug_bs_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bs_stamps), sizeof(unsigned long long) * 64 * 8);
+}
 extern "C" int droid_debug_chol_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_stamps), sizeof(unsigned long long) * 64 * 16);
 }

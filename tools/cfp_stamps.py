@@ -27,3 +27,10 @@ for kp in range(0, 24):
         r = st[kp, wg]
         seq = [r[11], r[12], r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[13]]
         print(f"col {kp:2d} wg {wg}: " + " ".join(f"{(v - t0) / 100:7.2f}" for v in seq))
+buf2 = (ctypes.c_ulonglong * (64 * 8))()
+lib.droid_debug_bs_stamps(buf2)
+bs = np.array(buf2[:], dtype=np.int64).reshape(64, 8)
+t0 = bs[23, 0]
+print("back-substitution, per block column j: start, last x seen, mat-vec done, after sync, solved, published (us)")
+for j in range(23, -1, -1):
+    print(f"j {j:2d}: " + " ".join(f"{(v - t0) / 100:7.2f}" for v in bs[j, :6]))
