@@ -303,9 +303,9 @@ def main():
         nk = deg + 1
         schur_flops = float(np.sum((6 * nk) * (6 * nk + 1) * HW + 6 * nk * HW)) * (E_l / max(1, len(prob.ii)))
         kernels = [
-            flop("droid::chol_step_kernel", "factor", n ** 3 / 3.0, FP64_VEC_PEAK_TFLOPS,
-                 "fp64 Cholesky of the (6P)^2 reduced camera system, n^3/3 flops over ceil(n/64) dependent "
-                 "launches: a pivot-latency chain, priced against the fp64 vector/MFMA peak"),
+            flop("droid::chol_factor_persistent_kernel", "factor", n ** 3 / 3.0, FP64_VEC_PEAK_TFLOPS,
+                 "fp64 Cholesky of the (6P)^2 reduced camera system in one launch, n^3/3 flops over ceil(n/64) "
+                 "dependent block columns: a pivot-latency chain, priced against the fp64 vector/MFMA peak"),
             hbm("droid::ba_lin_kernel<true>", "linearize", 16.0 * E_l * HW + 16.0 * M_l * HW + 56.0 * Nk,
                 "compulsory bytes of one BA iteration (16*E*HW + 16*M*HW + 56*N)"),
             flop("droid::ba_schur_fused_kernel<false>", "schur", schur_flops, 157.3,
