@@ -365,6 +365,41 @@ __device__ __forceinline__ void block_update16(f64x4& acc, const lds_f64* A, con
 //     then wave 0 updates block (p+1,p+1) and factors it while the other waves apply the
 //     remaining rank-16 updates of the diagonal tile and finish column p+1 of the tile to solve
 //     (its rank-64 update was deferred to this slot, where the matrix pipe is otherwise idle).
+// hand-off flags of the single-launch factorisation (agent scope = sc1: other XCDs see them)
+constexpr int CFP_SPIN_LIMIT = 1 << 20;
+
+__device__ __forceinline__ int cfp_load(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cfp_store(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// 16-column strip `sp` of a 64x64 tile (rows r0.., columns kc0 + 16*sp ..) -> LDS, by a 256-thread group, with
+// sc1 loads (data handed over by another workgroup of the running kernel): two 16-byte loads per thread.
+__device__ __forceinline__ void load_strip64(lds_f64* __restrict__ dst, const gbl_f64* __restrict__ S, int ld,
+                                             int r0, int kc0, int sp, int row_begin, int row_end) {
+  const int t = threadIdx.x & 255;
+  f64x2 v[2];
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int u = it * 256 + t;
+    const int i = u >> 3, j = 16 * sp + (u & 7) * 2;
+    const bool ok = (r0 + i >= row_begin) && (r0 + i < row_end);
+    const gbl_f64* p = S + (size_t)(ok ? r0 + i : r0) * ld + kc0 + j;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[it]) : "v"(p) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    asm volatile("" : "+v"(v[it]));
+    const int u = it * 256 + t;
+    const int i = u >> 3, j = 16 * sp + (u & 7) * 2;
+    if (!((r0 + i >= row_begin) && (r0 + i < row_end))) v[it] = (f64x2){0.0, 0.0};
+    *(lds_f64x2*)(&dst[i * LDP + j]) = v[it];
+  }
+}
+
 // LDS tiles of a factorisation workgroup (145 KB: one workgroup per CU).  Declared at namespace scope so
 // that the step body can be a real function of the single-launch kernel without passing LDS arrays
 // around as generic pointers.
@@ -381,7 +416,8 @@ __shared__ double g_cholIdn[256];
 template <bool PERSIST>
 __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld, int k, int bi, int bj,
                                           int* __restrict__ fail, double lm, double ep,
-                                          gbl_f64* __restrict__ Ldiag) {
+                                          gbl_f64* __restrict__ Ldiag, int* __restrict__ done,
+                                          int* __restrict__ abortf) {
   lds_f64* const B0 = DROID_LDS(g_cholB0);      // L[bi,k]          (workgroup-local tiles, see their declaration)
   lds_f64* const B1 = DROID_LDS(g_cholB1);      // L[bj,k]
   lds_f64* const B2 = DROID_LDS(g_cholB2);      // the diagonal tile D -> L
@@ -479,12 +515,57 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
 #pragma unroll
   for (int i = 0; i < 3; i++)
     if (i < ndef) frag_load_tile(dacc[i], S, ld, r0, c0, dg, (wave >= 5) ? i + 1 : wave, nrows, n, diag);
-  if (k >= 0) {
-    if (grp == 0) load_tile64<PERSIST>(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
-    else load_tile64<PERSIST>(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
+  if (!PERSIST && k >= 0) {
+    if (grp == 0) load_tile64(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
+    else load_tile64(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
   }
-  __syncthreads();
-  STAMP(1);
+  if (PERSIST && k >= 0) {
+    // The two panel tiles arrive in 16-column strips (their producers publish a strip as soon as it is solved):
+    // strips 0..2 and their rank-16 updates overlap with the producers' remaining work, only the last strip's
+    // load and update stay in front of the first pivot block.  done[row] = 4*column + strip of the last strip out.
+    for (int sp = 0; sp < 4; sp++) {
+      if (t < 64) {
+        const int* pf = (t == 0) ? &done[bi] : ((t == 1 && bi != kp) ? &done[kp] : nullptr);
+        bool sat = (pf == nullptr);
+        int spins = 0;
+        bool dead = false;
+        while (true) {
+          if (!sat) sat = cfp_load(pf) >= 4 * k + sp;
+          if (__all(sat)) break;
+          spins++;
+          if (spins > CFP_SPIN_LIMIT || ((spins & 255) == 0 && __any(cfp_load(abortf) == 1))) {
+            dead = true;  // never hang: the caller sees `abort` before the next tile, the result is discarded
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (t == 0 && dead) {
+          cfp_store(abortf, 1);
+          atomicExch(fail, 1);
+        }
+      }
+      __syncthreads();
+      if (grp == 0) load_strip64(B1, S, ld, c0, k * NB, sp, c0, n);
+      else load_strip64(B0, S, ld, r0, k * NB, sp, r0, nrows);
+      __syncthreads();
+      if (sp == 3) STAMP(1);
+      if (sp == 3 && wave == 0) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        if (i < ntile) {
+          const int rg = (code[i] >> 2) & 3, nt = code[i] & 3;
+          if (code[i] & 0x10) {
+            if (solve_rows) block_update16(tacc[i], &B0[(16 * rg) * LDP + 16 * sp], &B1[(16 * nt) * LDP + 16 * sp]);
+          } else {
+            block_update16(tacc[i], &B1[(16 * rg) * LDP + 16 * sp], &B1[(16 * nt) * LDP + 16 * sp]);
+          }
+        }
+      }
+    }
+  } else {
+    __syncthreads();
+    STAMP(1);
+  }
   auto store_solve = [&](const f64x4& a, int rg, int nt) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {  // tile to solve; the diagonal workgroup keeps only the rows below the tile
@@ -502,11 +583,11 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
       const bool isT = (code[i] & 0x10) != 0;
       if (isT) {
         if (solve_rows) {
-          if (k >= 0) strip_update_tile(tacc[i], B0, B1, rg, nt);
+          if (!PERSIST && k >= 0) strip_update_tile(tacc[i], B0, B1, rg, nt);
           store_solve(tacc[i], rg, nt);
         }
       } else {
-        if (k >= 0) strip_update_tile(tacc[i], B1, B1, rg, nt);
+        if (!PERSIST && k >= 0) strip_update_tile(tacc[i], B1, B1, rg, nt);
 #pragma unroll
         for (int e = 0; e < 4; e++) {  // diagonal tile: strict upper part 0, identity beyond wk
           const int li = 16 * rg + fg + 4 * e, lj = 16 * nt + fr;
@@ -540,6 +621,25 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
     if (p == 0) STAMP(10);
     __syncthreads();
     if (p == 0) STAMP(5);
+    if (PERSIST && solve_rows && wave == 4) {
+      // columns 16p..16p+15 of the solved tile are final: wave 4 (little else to do) writes them through and
+      // publishes the strip; the next block column's workgroups start their rank-16 updates on it right away
+      const int rb = max(r0, c0 + wk), re = min(r0 + NB, nrows);
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const int u = it * 64 + lane;
+        const int i = u >> 3, j = 16 * p + (u & 7) * 2;
+        if (r0 + i >= rb && r0 + i < re && j < wk) {
+          gbl_f64* gp = &S[(size_t)(r0 + i) * ld + c0 + j];
+          const f64x2 v = *(const lds_f64x2*)&BT[i * LDP + j];
+          if (j + 1 < wk) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(gp), "v"(v) : "memory");
+          else gstore<true>(gp, v[0]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) cfp_store(&done[bi], 4 * kp + p);
+      if (p == 3) STAMP(9);
+    }
     if (p == 3) break;
     const int q = p + 1;
     if (wave == 0) {  // the pivot chain: next diagonal block, then its factorisation
@@ -599,15 +699,16 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
       if (PERSIST) store_tile64(Ldiag + (size_t)kp * NB * NB, B2, NB, 0, 0, 0, NB, NB, false);
       else store_tile64(S, B2, ld, c0, c0, c0, c0 + wk, wk, true);
     }
-  } else if (solve_rows) {
-    store_tile64<PERSIST>(S, BT, ld, r0, c0, max(r0, c0 + wk), min(r0 + NB, nrows), wk, false);
+  } else if (solve_rows && !PERSIST) {  // (single launch: the strips went out one by one)
+    store_tile64(S, BT, ld, r0, c0, max(r0, c0 + wk), min(r0 + NB, nrows), wk, false);
   }
-  STAMP(9);
+  if (!PERSIST) STAMP(9);
 }
 
 __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, int n, int ld, int k,
                                                         int* __restrict__ fail, double lm, double ep) {
-  chol_tile<false>((gbl_f64*)S, n, ld, k, k + 1 + (int)blockIdx.x, k + 1 + (int)blockIdx.y, fail, lm, ep, nullptr);
+  chol_tile<false>((gbl_f64*)S, n, ld, k, k + 1 + (int)blockIdx.x, k + 1 + (int)blockIdx.y, fail, lm, ep, nullptr,
+                   nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -617,10 +718,11 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
 //   * static ownership: lower-triangle tiles in column-major order, tile idx -> workgroup
 //     idx % grid; a workgroup applies every step to its own tiles, so a tile's intermediate
 //     versions never change hands (and panel tiles come first in every workgroup's step);
-//   * data flow instead of barriers: done[i] = last final tile L[i, c] of block row i,
-//     dver[j] = trailing updates applied to the diagonal tile (j, j) by its owner (0 = damped).
-//     Tile (bi, bj) at step k waits for done[bi] >= k and done[bj] >= k, a panel tile also for
-//     dver[k+1] >= k; nothing waits for unrelated trailing tiles (look-ahead comes for free);
+//   * data flow instead of barriers: done[i] = 4*c + s for the last 16-column strip s of the last final tile
+//     L[i, c] of block row i, dver[j] = trailing updates applied to the diagonal tile (j, j) by its owner
+//     (0 = damped).  A trailing tile (bi, bj) at step k waits for done[bi], done[bj] >= 4k+3; a panel tile
+//     waits for dver[k+1] >= k and then takes the two panel tiles strip by strip as they are published;
+//     nothing waits for unrelated trailing tiles (look-ahead comes for free);
 //   * hand-off without cache maintenance: every tile store is written through (sc1), tiles of other
 //     workgroups are read with sc1 loads, the flags likewise: store, s_waitcnt vmcnt(0), barrier, flag |
 //     flag poll, barrier, loads.  Rows are 128-byte aligned (ld % 16 == 0) so tiles of different
@@ -629,21 +731,14 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
 //     column read the unfactored tile at their own pace;
 //   * every spin is bounded: a stalled grid raises `abort`, reports a failed factorisation and
 //     drains (it cannot happen with a resident grid; the GPU is never left hanging).
-constexpr int CFP_SPIN_LIMIT = 1 << 20;
-
-__device__ __forceinline__ int cfp_load(const int* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void cfp_store(int* p, int v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // One tile of one step.  NOT inlined into the step loops: inlined, the loop-invariant lane offsets of the
 // whole body are hoisted in front of the loops and held (or spilled) across them.
 __device__ __attribute__((noinline)) void chol_tile_persist(double* __restrict__ S, int n, int ld, int k, int bi,
                                                             int bj, int* __restrict__ fail, double lm, double ep,
-                                                            double* __restrict__ Ldiag) {
-  chol_tile<true>((gbl_f64*)S, n, ld, k, bi, bj, fail, lm, ep, (gbl_f64*)Ldiag);
+                                                            double* __restrict__ Ldiag, int* __restrict__ done,
+                                                            int* __restrict__ abortf) {
+  chol_tile<true>((gbl_f64*)S, n, ld, k, bi, bj, fail, lm, ep, (gbl_f64*)Ldiag, done, abortf);
 }
 
 __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __restrict__ S, int n, int ld,
@@ -697,14 +792,17 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
       if (t < 64) {
         bool ok = true;
         if (k >= 0) {
+          // plain tile: both panel tiles complete (all four strips); panel tile: only the diagonal tile's
+          // version here, the strips are awaited inside the body
           const int* p = nullptr;
-          if (t == 0) p = &done[bi];
-          else if (t == 1 && bj != bi) p = &done[bj];
-          else if (t == 2 && panel && bi != bj) p = &dver[bj];
+          int need = 4 * k + 3;
+          if (t == 0 && !panel) p = &done[bi];
+          else if (t == 1 && !panel && bj != bi) p = &done[bj];
+          else if (t == 2 && panel && bi != bj) { p = &dver[bj]; need = k; }
           bool sat = (p == nullptr);
           int spins = 0;
           while (true) {
-            if (!sat) sat = cfp_load(p) >= k;
+            if (!sat) sat = cfp_load(p) >= need;
             if (__all(sat)) break;
             spins++;
             if (spins > CFP_SPIN_LIMIT || ((spins & 255) == 0 && __any(cfp_load(abortf) == 1))) {
@@ -727,16 +825,13 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
       PSTAMP(12);
       __syncthreads();  // also: the previous tile's LDS reads are over
       if (s_abort) return;
-      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag);
-      if (panel || bi == bj) {  // publish: final tile of row bi, or the next version of a diagonal tile
+      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf);
+      if (!panel && bi == bj) {  // publish the next version of a diagonal tile (panel tiles publish their strips)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's write-through stores are acknowledged
         __syncthreads();
-        if (t == 0) {
-          if (panel) cfp_store(&done[bi], kp);
-          else cfp_store(&dver[bj], k + 1);
-        }
-        PSTAMP(13);
+        if (t == 0) cfp_store(&dver[bj], k + 1);
       }
+      PSTAMP(13);
     }
     colstart += nrb - kp;
   }
