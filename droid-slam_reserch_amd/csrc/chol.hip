@@ -1100,7 +1100,10 @@ void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* f
   if (chol_single_launch(sys, n, ld, flags, ldiag)) {
     int total = 0;
     for (int j = 0; j < nb; j++) total += nrb - j;
-    const int grid = total < chol_resident_workgroups() ? total : chol_resident_workgroups();
+    int cap = chol_resident_workgroups();
+    static const int env_cap = getenv("DROID_CHOL_GRID") ? atoi(getenv("DROID_CHOL_GRID")) : 0;  // diagnostics
+    if (env_cap >= 8 && env_cap < cap) cap = env_cap;
+    const int grid = total < cap ? total : cap;
     hipLaunchKernelGGL(chol_factor_persistent_kernel, dim3(grid), dim3(512), 0, s, sys, n, ld, fail_flag, lm,
                        ep, flags, ldiag);
     return;

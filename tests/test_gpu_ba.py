@@ -44,7 +44,9 @@ def test_chol_solve_matches_numpy(backends):
     import ctypes
     lib = backends._lib.load()
     rng = np.random.default_rng(0)
-    for n in (6, 42, 64, 65, 130, 378, 700):
+    # 6..65: one block column (per-step kernels); 130..: the single-launch factorisation; 1536: the rhs row is a
+    # block row of its own; 2050: 561 tiles on 256 workgroups (several tiles per workgroup and step), odd width
+    for n in (6, 42, 64, 65, 130, 378, 700, 1536, 2051):
         A = rng.normal(size=(n, n + 8))
         A = A @ A.T + n * 0.1 * np.eye(n)
         b = rng.normal(size=n)
@@ -76,6 +78,35 @@ def test_chol_failure_flag(backends):
                          torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert int(flag.item()) == 1
+
+
+def test_chol_failure_flag_single_launch(backends):
+    """A non-positive pivot deep inside the single-launch factorisation (block column 9 of 12): the flag is
+    raised, nothing hangs, and a following well-posed solve on the same scratch is unaffected."""
+    torch = _torch()
+    lib = backends._lib.load()
+    n = 760
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(n, n + 8))
+    A = A @ A.T + n * 0.1 * np.eye(n)
+    b = rng.normal(size=n)
+    bad = A.copy()
+    bad[600, 600] = -1.0
+    x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros((n + 1) * (n + 16) + 4096 * (n // 64 + 1) + n // 64 + 16, dtype=torch.float64, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    db = torch.from_numpy(b).cuda()
+    lib.droid_chol_solve(torch.from_numpy(bad).cuda().data_ptr(), db.data_ptr(), x.data_ptr(), n, scratch.data_ptr(),
+                         flag.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+    lib.droid_chol_solve(torch.from_numpy(A).cuda().data_ptr(), db.data_ptr(), x.data_ptr(), n, scratch.data_ptr(),
+                         flag.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    ref = np.linalg.solve(A, b)
+    assert np.abs(x.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-10
 
 
 def test_reduced_system_matches_oracle(backends, oracle, synth):
