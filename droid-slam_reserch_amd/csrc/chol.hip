@@ -1001,7 +1001,10 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
       z -= (a0 + a1) + (a2 + a3);
     }
     cur ^= 1;
-    if (k == j + 1) BSTAMP(2);
+    if (k == j + 1) {
+      BSTAMP(2);
+      break;  // nothing left to prefetch: wave 0 goes straight into the diagonal solve
+    }
     __syncthreads();  // tile k-1 landed, tile k consumed
     if (dead) return;
   }
