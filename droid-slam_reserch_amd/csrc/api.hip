@@ -255,6 +255,7 @@ int droid_ba_profile_iteration(float* poses, float* disps, const float* intrinsi
   if (v.n > 0 && E <= 0) {  // presets of x and the hand-off flags (with edges the assemble kernel did it)
     (void)hipMemsetAsync(v.xsol, 0xFF, sizeof(double) * (size_t)v.n, s);
     (void)hipMemsetAsync(v.bs_flags, 0xFF, sizeof(int) * chol_flag_words(v.n), s);
+    (void)hipMemsetAsync(v.ldiag + chol_lfin_offset(v.n), 0xFF, sizeof(double) * chol_tiles(v.n) * CHOL_NB * CHOL_NB, s);
   }
   launch_chol_factor(v.sys, v.n, v.ld, (double)lm, (double)ep, v.hdr + HDR_CHOL_FAIL, v.bs_flags, v.ldiag, s);
   (void)hipEventRecord(ev[5], s);
@@ -294,6 +295,11 @@ int droid_ba_status(const void* workspace, void* stream, int* status_out, int* d
   if (status_out) *status_out = hdr[HDR_STATUS];
   if (depth_slots_out) *depth_slots_out = hdr[HDR_M];
   return DROID_OK;
+}
+
+size_t droid_chol_scratch_doubles(int n) {
+  if (n <= 0) return 0;
+  return (size_t)(n + 1) * chol_ld(n) + chol_ldiag_doubles(n) + (chol_flag_words(n) + 1) / 2 + 16;
 }
 
 int droid_chol_solve(const double* A, const double* b, double* x, int n, double* scratch,

@@ -14,7 +14,16 @@ constexpr int CHOL_NB = 64;                      // Cholesky block size
 __host__ __device__ inline int chol_ld(int n) { return (n + 1 + 15) & ~15; }
 // ints of hand-off flags (done[], dver[], abort) and doubles of factored diagonal tiles for an n x n solve
 __host__ __device__ inline size_t chol_flag_words(int n) { return 2 * ((size_t)(n + 1 + CHOL_NB - 1) / CHOL_NB) + 8; }
-__host__ __device__ inline size_t chol_ldiag_doubles(int n) { return ((size_t)(n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
+// lower-triangle tiles of the augmented system in column-major order: tile (bi, bj), bi >= bj
+__host__ __device__ inline int chol_tile_index(int nrb, int bi, int bj) { return bj * nrb - bj * (bj - 1) / 2 + (bi - bj); }
+__host__ __device__ inline size_t chol_tiles(int n) {
+  const int nb = (n + CHOL_NB - 1) / CHOL_NB, nrb = (n + 1 + CHOL_NB - 1) / CHOL_NB;
+  return (size_t)chol_tile_index(nrb, nb, nb);  // = sum_{j<nb} (nrb - j)
+}
+// `ldiag` scratch: [nb] factored diagonal tiles, then [chol_tiles] 64x64 slots `lfin` for the final panel tiles as
+// the panel chain hands them over (data-tagged: preset to 0xFF bytes, a strip is there when its bytes are not)
+__host__ __device__ inline size_t chol_lfin_offset(int n) { return ((size_t)(n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
+__host__ __device__ inline size_t chol_ldiag_doubles(int n) { return chol_lfin_offset(n) + chol_tiles(n) * CHOL_NB * CHOL_NB; }
 
 enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4, HDR_WORDS = 16 };
 enum { STATUS_BAD_INDEX = 1, STATUS_ETA_ROWS = 2, STATUS_CHOL_FAIL = 4 };
@@ -51,7 +60,7 @@ struct BaView {
   double* xsol;            // [ld] solve scratch / solution
   float* dx;               // [P][6]
   int* bs_flags;           // [chol_flag_words(n)] hand-off flags of the single-launch factorisation
-  double* ldiag;           // [ceil(n/64)][64][64] factored diagonal tiles of the single-launch factorisation
+  double* ldiag;           // [ceil(n/64)][64][64] factored diagonal tiles, then the hand-over slots of the panel tiles
 };
 
 struct BaSizes {
@@ -114,6 +123,8 @@ __host__ __device__ inline int solver_preset_words(const BaView& v) {
   return (int)((reinterpret_cast<const char*>(v.bs_flags) - reinterpret_cast<const char*>(v.xsol)) / 4 +
                (long)chol_flag_words(v.n));
 }
+// 32 KB blocks of the panel-tile hand-over slots (ldiag + chol_lfin_offset), preset to 0xFF bytes the same way
+__host__ __device__ inline int solver_preset_tiles(const BaView& v) { return v.n > 0 ? (int)chol_tiles(v.n) : 0; }
 
 // kernels' launchers (ba_kernels.hip / chol.hip)
 void launch_prep(const BaView& v, const int64_t* ii, const int64_t* jj, hipStream_t s);

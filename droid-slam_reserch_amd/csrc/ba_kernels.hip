@@ -568,8 +568,14 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaView v, const float* 
     // factorisation): solution vector and hand-off flags to 0xFF bytes, the failure flag to 0
     unsigned* w = reinterpret_cast<unsigned*>(v.xsol);
     const int words = solver_preset_words(v);
-    for (int i = (e - v.E) * 1024 + t; i < min(words, (e - v.E + 1) * 1024); i += 64) w[i] = 0xFFFFFFFFu;
-    if (e == v.E && t == 0) v.hdr[HDR_CHOL_FAIL] = 0;
+    const int nw = (words + 1023) / 1024;
+    if (e - v.E < nw) {
+      for (int i = (e - v.E) * 1024 + t; i < min(words, (e - v.E + 1) * 1024); i += 64) w[i] = 0xFFFFFFFFu;
+      if (e == v.E && t == 0) v.hdr[HDR_CHOL_FAIL] = 0;
+    } else {  // one 64x64 hand-over slot of the panel tiles per workgroup
+      uint4* q = reinterpret_cast<uint4*>(v.ldiag + chol_lfin_offset(v.n) + (size_t)(e - v.E - nw) * CHOL_NB * CHOL_NB);
+      for (int i = t; i < CHOL_NB * CHOL_NB / 2; i += 64) q[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
     return;
   }
   const int64_t i64 = ii[e], j64 = jj[e];
@@ -1268,7 +1274,7 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
       break;
     case 1:
       if (v.E > 0)
-        hipLaunchKernelGGL(ba_assemble_kernel, dim3(v.E + (solver_preset_words(v) + 1023) / 1024), dim3(64), 0, s, v, poses, ii, jj);
+        hipLaunchKernelGGL(ba_assemble_kernel, dim3(v.E + (solver_preset_words(v) + 1023) / 1024 + solver_preset_tiles(v)), dim3(64), 0, s, v, poses, ii, jj);
       break;
     case 2:
       if (depth) {

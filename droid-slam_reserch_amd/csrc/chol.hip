@@ -375,27 +375,51 @@ __device__ __forceinline__ void cfp_store(int* p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// 16-column strip `sp` of a 64x64 tile (rows r0.., columns kc0 + 16*sp ..) -> LDS, by a 256-thread group, with
-// sc1 loads (data handed over by another workgroup of the running kernel): two 16-byte loads per thread.
-__device__ __forceinline__ void load_strip64(lds_f64* __restrict__ dst, const gbl_f64* __restrict__ S, int ld,
-                                             int r0, int kc0, int sp, int row_begin, int row_end) {
+// 16-column strip `sp` of a final panel tile -> LDS, by a 256-thread group, from the tile's hand-over slot
+// (64x64, row pitch 64).  The slot is data-tagged: it was preset to 0xFF bytes, the producer writes the strip with
+// 16-byte sc1 stores as soon as it is solved, and every thread here re-reads its two 16-byte units until none of
+// the four values is the preset pattern.  No flag, no store acknowledgement on the producer side (that hand-off
+// took 3 us of the 14 per block column).  Rows outside [row_begin, row_end) are not part of the tile: zeros.
+constexpr long long CFP_TAG = -1LL;  // 0xFF bytes; a computed NaN never has this payload
+__device__ __forceinline__ void load_strip64(lds_f64* __restrict__ dst, const gbl_f64* __restrict__ slot, int r0,
+                                             int sp, int row_begin, int row_end, int* __restrict__ fail,
+                                             int* __restrict__ abortf) {
   const int t = threadIdx.x & 255;
   f64x2 v[2];
+  bool ok[2];
+  const gbl_f64* p[2];
 #pragma unroll
   for (int it = 0; it < 2; it++) {
     const int u = it * 256 + t;
     const int i = u >> 3, j = 16 * sp + (u & 7) * 2;
-    const bool ok = (r0 + i >= row_begin) && (r0 + i < row_end);
-    const gbl_f64* p = S + (size_t)(ok ? r0 + i : r0) * ld + kc0 + j;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[it]) : "v"(p) : "memory");
+    ok[it] = (r0 + i >= row_begin) && (r0 + i < row_end);
+    p[it] = slot + (size_t)(ok[it] ? i : 0) * NB + j;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int spins = 0;
+  while (true) {
+#pragma unroll
+    for (int it = 0; it < 2; it++)
+      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[it]) : "v"(p[it]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bool there = true;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      asm volatile("" : "+v"(v[it]));
+      if (ok[it] && (__double_as_longlong(v[it][0]) == CFP_TAG || __double_as_longlong(v[it][1]) == CFP_TAG)) there = false;
+    }
+    if (there) break;
+    if (++spins > CFP_SPIN_LIMIT || ((spins & 255) == 0 && cfp_load(abortf) == 1)) {
+      cfp_store(abortf, 1);  // never hang: the caller sees `abort` before its next tile, the result is discarded
+      atomicExch(fail, 1);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
 #pragma unroll
   for (int it = 0; it < 2; it++) {
-    asm volatile("" : "+v"(v[it]));
     const int u = it * 256 + t;
     const int i = u >> 3, j = 16 * sp + (u & 7) * 2;
-    if (!((r0 + i >= row_begin) && (r0 + i < row_end))) v[it] = (f64x2){0.0, 0.0};
+    if (!ok[it]) v[it] = (f64x2){0.0, 0.0};
     *(lds_f64x2*)(&dst[i * LDP + j]) = v[it];
   }
 }
@@ -520,33 +544,15 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
     else load_tile64(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
   }
   if (PERSIST && k >= 0) {
-    // The two panel tiles arrive in 16-column strips (their producers publish a strip as soon as it is solved):
-    // strips 0..2 and their rank-16 updates overlap with the producers' remaining work, only the last strip's
-    // load and update stay in front of the first pivot block.  done[row] = 4*column + strip of the last strip out.
+    // The two panel tiles arrive in 16-column strips (their producers write a strip into the tile's data-tagged
+    // hand-over slot as soon as it is solved): strips 0..2 and their rank-16 updates overlap with the producers'
+    // remaining work, only the last strip's load and update stay in front of the first pivot block.
+    const int nrb = (nrows + NB - 1) / NB;
+    const gbl_f64* slot1 = Ldiag + chol_lfin_offset(n) + (size_t)chol_tile_index(nrb, kp, k) * NB * NB;  // L[kp,k]
+    const gbl_f64* slot0 = Ldiag + chol_lfin_offset(n) + (size_t)chol_tile_index(nrb, bi, k) * NB * NB;  // L[bi,k]
     for (int sp = 0; sp < 4; sp++) {
-      if (t < 64) {
-        const int* pf = (t == 0) ? &done[bi] : ((t == 1 && bi != kp) ? &done[kp] : nullptr);
-        bool sat = (pf == nullptr);
-        int spins = 0;
-        bool dead = false;
-        while (true) {
-          if (!sat) sat = cfp_load(pf) >= 4 * k + sp;
-          if (__all(sat)) break;
-          spins++;
-          if (spins > CFP_SPIN_LIMIT || ((spins & 255) == 0 && __any(cfp_load(abortf) == 1))) {
-            dead = true;  // never hang: the caller sees `abort` before the next tile, the result is discarded
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (t == 0 && dead) {
-          cfp_store(abortf, 1);
-          atomicExch(fail, 1);
-        }
-      }
-      __syncthreads();
-      if (grp == 0) load_strip64(B1, S, ld, c0, k * NB, sp, c0, n);
-      else load_strip64(B0, S, ld, r0, k * NB, sp, r0, nrows);
+      if (grp == 0) load_strip64(B1, slot1, c0, sp, c0, n, fail, abortf);
+      else load_strip64(B0, slot0, r0, sp, r0, nrows, fail, abortf);
       __syncthreads();
       if (sp == 3) STAMP(1);
       if (sp == 3 && wave == 0) __builtin_amdgcn_s_setprio(3);
@@ -625,8 +631,18 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
       // columns 16p..16p+15 of the solved tile are final: wave 4 (little else to do) writes them through and
       // publishes the strip; the next block column's workgroups start their rank-16 updates on it right away
       const int rb = max(r0, c0 + wk), re = min(r0 + NB, nrows);
+      gbl_f64* slot = Ldiag + chol_lfin_offset(n) + (size_t)chol_tile_index((nrows + NB - 1) / NB, bi, kp) * NB * NB;
 #pragma unroll
-      for (int it = 0; it < 8; it++) {
+      for (int it = 0; it < 8; it++) {  // first the hand-over slot the panel chain polls ...
+        const int u = it * 64 + lane;
+        const int i = u >> 3, j = 16 * p + (u & 7) * 2;
+        if (r0 + i >= rb && r0 + i < re && wk == NB) {
+          const f64x2 v = *(const lds_f64x2*)&BT[i * LDP + j];
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&slot[i * NB + j]), "v"(v) : "memory");
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 8; it++) {  // ... then the matrix itself (trailing tiles and the back-substitution read it)
         const int u = it * 64 + lane;
         const int i = u >> 3, j = 16 * p + (u & 7) * 2;
         if (r0 + i >= rb && r0 + i < re && j < wk) {
@@ -1144,6 +1160,8 @@ void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double*
     launch_chol_backsolve(sys, n, ld, x, flags, ldiag, fail_flag, s);
     return;
   }
+  if (ldiag)  // hand-over slots of the panel tiles: data-tagged, 0xFF bytes = not there yet
+    (void)hipMemsetAsync(ldiag + chol_lfin_offset(n), 0xFF, sizeof(double) * chol_tiles(n) * NB * NB, s);
   const size_t xbytes = sizeof(double) * (size_t)n, fbytes = flags ? sizeof(int) * chol_flag_words(n) : 0;
   char* xb = reinterpret_cast<char*>(x);
   char* fb = reinterpret_cast<char*>(flags);

@@ -151,8 +151,9 @@ int droid_ba_status(const void *workspace, void *stream, int *status_out, int *d
 
 /* Dense SPD solve used by the BA (exposed for tests): A [n,n] fp64 row-major (lower triangle
  * read, destroyed), b [n] fp64 -> x [n] fp64.  fail_flag (device int) is set to 1 when a pivot
- * is not positive.  scratch (128-byte aligned): >= (n+1)*(n+16) + 4096*(n/64+1) + n/64 + 16 doubles
- * (the augmented system with 128-byte rows, the factored 64x64 diagonal tiles, hand-off flags). */
+ * is not positive.  scratch (128-byte aligned): >= droid_chol_scratch_doubles(n) doubles (the augmented system
+ * with 128-byte rows, the factored diagonal tiles, hand-over slots of the panel tiles, hand-off flags). */
+size_t droid_chol_scratch_doubles(int n);
 int droid_chol_solve(const double *A, const double *b, double *x, int n, double *scratch,
                      int *fail_flag, void *stream);
 

@@ -52,7 +52,7 @@ def test_chol_solve_matches_numpy(backends):
         b = rng.normal(size=n)
         dA, db = torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()
         x = torch.zeros(n, dtype=torch.float64, device="cuda")
-        scratch = torch.zeros((n + 1) * (n + 16) + 4096 * (n // 64 + 1) + n // 64 + 16, dtype=torch.float64, device="cuda")
+        scratch = torch.zeros(lib.droid_chol_scratch_doubles(n), dtype=torch.float64, device="cuda")
         flag = torch.zeros(1, dtype=torch.int32, device="cuda")
         rc = lib.droid_chol_solve(dA.data_ptr(), db.data_ptr(), x.data_ptr(), n, scratch.data_ptr(),
                                   flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -72,7 +72,7 @@ def test_chol_failure_flag(backends):
     A = -np.eye(n)
     dA, db = torch.from_numpy(A).cuda(), torch.ones(n, dtype=torch.float64, device="cuda")
     x = torch.zeros(n, dtype=torch.float64, device="cuda")
-    scratch = torch.zeros((n + 1) * (n + 16) + 4096 * (n // 64 + 1) + n // 64 + 16, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(lib.droid_chol_scratch_doubles(n), dtype=torch.float64, device="cuda")
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
     lib.droid_chol_solve(dA.data_ptr(), db.data_ptr(), x.data_ptr(), n, scratch.data_ptr(), flag.data_ptr(),
                          torch.cuda.current_stream().cuda_stream)
@@ -93,7 +93,7 @@ def test_chol_failure_flag_single_launch(backends):
     bad = A.copy()
     bad[600, 600] = -1.0
     x = torch.zeros(n, dtype=torch.float64, device="cuda")
-    scratch = torch.zeros((n + 1) * (n + 16) + 4096 * (n // 64 + 1) + n // 64 + 16, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(lib.droid_chol_scratch_doubles(n), dtype=torch.float64, device="cuda")
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
     db = torch.from_numpy(b).cuda()

@@ -4,12 +4,14 @@ import sys, ctypes
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/droid-slam_reserch_amd")
 import numpy as np, torch
 lib = ctypes.CDLL("/root/repo/tools/libs/lib_stamps.so")
+lib.droid_chol_scratch_doubles.argtypes = [ctypes.c_int]
+lib.droid_chol_scratch_doubles.restype = ctypes.c_size_t
 n = 1530
 rng = np.random.default_rng(0)
 A = rng.normal(size=(n, n + 8)); A = A @ A.T + n * 0.1 * np.eye(n); b = rng.normal(size=n)
 dA, dbb = torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()
 x = torch.zeros(n, dtype=torch.float64, device="cuda")
-scratch = torch.zeros((n + 1) * (n + 16) + 4096 * (n // 64 + 1) + n // 64 + 16, dtype=torch.float64, device="cuda")
+scratch = torch.zeros(lib.droid_chol_scratch_doubles(n), dtype=torch.float64, device="cuda")
 flag = torch.zeros(1, dtype=torch.int32, device="cuda")
 vp = ctypes.c_void_p
 lib.droid_chol_solve.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp]

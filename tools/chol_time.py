@@ -10,7 +10,7 @@ rng = np.random.default_rng(0)
 B = rng.normal(size=(n, n)); A = B @ B.T + n * np.eye(n); b = rng.normal(size=n)
 dA0 = torch.from_numpy(A).cuda(); db = torch.from_numpy(b).cuda()
 x = torch.zeros(n, dtype=torch.float64, device="cuda"); flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-scratch = torch.zeros((n + 1) * (n + 16) + 4096 * (n // 64 + 1) + n // 64 + 16, dtype=torch.float64, device="cuda")
+scratch = torch.zeros(lib.droid_chol_scratch_doubles(n), dtype=torch.float64, device="cuda")
 def run():
     return lib.droid_chol_solve(dA0.data_ptr(), db.data_ptr(), x.data_ptr(), n, scratch.data_ptr(), flag.data_ptr(), None)
 for _ in range(3): run()
