@@ -207,6 +207,17 @@ def bench_corr(args, rank, world, dev, prob):
                                        tflops=pixa * alt_flop_per_pix / ms_pyr / 1e9,
                                        frac_of_fp32_peak=pixa * alt_flop_per_pix / ms_pyr / 1e9 / 157.3,
                                        kernel="altcorr_pyramid_mfma<3>: AltCorrBlock.corr_fn in one launch over (pyramid, ii, jj)")
+    # reproject + motion features of the update operator (DepthVideo.reproject + factor_graph.py:203-205), fused:
+    # per pixel 4 B disparity + 8 B target in, 8 B coords + 4 B valid + 16 B features out
+    Ea = len(prob.ii)
+    iia, jja = to_dev(prob.ii, dev), to_dev(prob.jj, dev)
+    pz, dz, kz = to_dev(prob.poses, dev), to_dev(prob.disps, dev), to_dev(prob.intrinsics, dev)
+    tg = torch.rand((Ea, H, W, 2), device=dev) * 64.0
+    ms_rp = timeit(lambda: db.reproject(pz, dz, kz, iia, jja, tg), 5)
+    out["reproject_motion"] = dict(gpix_per_s=Ea * H * W / ms_rp / 1e6, ms=ms_rp, edges=Ea, algorithmic_bytes_per_pix=40.0,
+                                   hbm_gbs=Ea * H * W * 40.0 / ms_rp / 1e6,
+                                   frac_of_8TBs=Ea * H * W * 40.0 / ms_rp / 1e6 / HBM_PEAK_GBS,
+                                   kernel="reproject_motion_kernel")
     return out
 
 

@@ -37,6 +37,9 @@ void launch_depth_filter(const float* poses, const float* disps, const float* in
                          float* counter, hipStream_t s);
 // chol.hip
 void launch_chol_pack(const double* A, const double* b, double* S, int n, int ld, hipStream_t s);
+void launch_reproject_motion(const float* poses, const float* disps, const float* intr, int intr_stride,
+                             const int64_t* ii, const int64_t* jj, const float* target, int E, int nbuf, int H,
+                             int W, float* coords, float* valid, float* motn, hipStream_t s);
 }  // namespace droid
 
 using namespace droid;
@@ -334,6 +337,19 @@ int droid_projmap(const float* poses, const float* disps, const float* intrinsic
   if (!poses || !disps || !intrinsics || !ii || !jj || !coords || !valid) return fail(DROID_E_ARG, "projmap: null %s", "pointer");
   launch_projmap(poses, disps, intrinsics, ii, jj, E, nbuf, H, W, coords, valid, (hipStream_t)stream);
   return check_hip("projmap");
+}
+
+int droid_reproject_motion(const float* poses, const float* disps, const float* intrinsics, int intr_stride,
+                           const int64_t* ii, const int64_t* jj, const float* target, int E, int nbuf, int H, int W,
+                           float* coords, float* valid, float* motn, void* stream) {
+  if (E < 0 || nbuf <= 0 || H <= 0 || W <= 0 || (intr_stride != 0 && intr_stride != 4))
+    return fail(DROID_E_ARG, "reproject_motion: bad %s", "sizes");
+  if (E == 0) return DROID_OK;
+  if (!poses || !disps || !intrinsics || !ii || !jj || !coords || !valid) return fail(DROID_E_ARG, "reproject_motion: null %s", "pointer");
+  if (motn && !target) return fail(DROID_E_ARG, "reproject_motion: motn needs %s", "target");
+  launch_reproject_motion(poses, disps, intrinsics, intr_stride, ii, jj, target, E, nbuf, H, W, coords, valid, motn,
+                          (hipStream_t)stream);
+  return check_hip("reproject_motion");
 }
 
 int droid_iproj(const float* poses, const float* disps, const float* intrinsics, int nm, int H,

@@ -102,6 +102,57 @@ __global__ __launch_bounds__(256) void projmap_kernel(
   valid[(size_t)e * HW + k] = (Xj[2] > DROID_MIN_DEPTH) ? 1.0f : 0.0f;
 }
 
+
+// reproject + motion features of the update operator, one pass:
+//   depth_video.py:150-158 `reproject` -> geom/projective_ops.py:96-125 `projective_transform`
+//   (back-projection with the SOURCE frame's intrinsics :99, Gij = Gj * Gi^-1 :102, stereo edges ii == jj use
+//   the fixed baseline (-0.1, 0, 0) :105, projection with the TARGET frame's intrinsics where a depth below
+//   0.5 * MIN_DEPTH is replaced by 1 :46-51, valid = depth > MIN_DEPTH = 0.2 :113 -- these are the Python-side
+//   constants, not the 0.25 of droid_kernels.cu), then factor_graph.py:203-205:
+//   motn = clamp(cat(coords1 - coords0, target - coords1), -64, 64) laid out [E,4,H,W].
+// One thread per pixel; coords/valid/motn rows are written with unit stride (motn planes are H*W apart).
+__global__ __launch_bounds__(256) void reproject_motion_kernel(
+    const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intrinsics,
+    int intr_stride, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+    const float* __restrict__ target, float* __restrict__ coords, float* __restrict__ valid,
+    float* __restrict__ motn, int nbuf, int H, int W) {
+  const int e = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W;
+  if (k >= HW) return;
+  const int64_t i64 = ii[e], j64 = jj[e];
+  const size_t o = (size_t)e * HW + k;
+  if (i64 < 0 || i64 >= nbuf || j64 < 0 || j64 >= nbuf) {  // edge with a bad index: zeros, no fault
+    reinterpret_cast<float2*>(coords)[o] = make_float2(0.f, 0.f);
+    valid[o] = 0.f;
+    if (motn)
+      for (int c = 0; c < 4; c++) motn[((size_t)e * 4 + c) * HW + k] = 0.f;
+    return;
+  }
+  const float* ki = intrinsics + (size_t)i64 * intr_stride;
+  const float* kj = intrinsics + (size_t)j64 * intr_stride;
+  const Intr Ki = {ki[0], ki[1], ki[2], ki[3]};
+  const Rel T = rel_pose<true>(poses, (int)i64, (int)j64);
+  const float u = (float)(k % W), v = (float)(k / W);
+  float Xj[4];
+  transform_pixel(Ki, T, u, v, disps[(size_t)i64 * HW + k], Xj);
+  const float Z = Xj[2];
+  const float d = 1.0f / ((Z < 0.5f * 0.2f) ? 1.0f : Z);
+  const float x = kj[0] * (Xj[0] * d) + kj[2];
+  const float y = kj[1] * (Xj[1] * d) + kj[3];
+  reinterpret_cast<float2*>(coords)[o] = make_float2(x, y);
+  valid[o] = (Z > 0.2f) ? 1.0f : 0.0f;  // the source point has depth 1 > MIN_DEPTH by construction
+  if (motn) {
+    const float2 tg = reinterpret_cast<const float2*>(target)[o];
+    auto clamp64 = [](float a) { return fminf(fmaxf(a, -64.0f), 64.0f); };
+    float* m = motn + (size_t)e * 4 * HW + k;
+    m[0] = clamp64(x - u);
+    m[HW] = clamp64(y - v);
+    m[2 * (size_t)HW] = clamp64(tg.x - x);
+    m[3 * (size_t)HW] = clamp64(tg.y - y);
+  }
+}
+
 // iproj_kernel dk:779-850
 __global__ __launch_bounds__(256) void iproj_kernel(const float* __restrict__ poses,
                                                     const float* __restrict__ disps,
@@ -180,6 +231,13 @@ void launch_projmap(const float* poses, const float* disps, const float* intr, c
   (void)hipMemsetAsync(valid, 0, sizeof(float) * (size_t)E * H * W, s);
   hipLaunchKernelGGL(projmap_kernel, dim3((H * W + 255) / 256, E), dim3(256), 0, s, poses, disps,
                      intr, ii, jj, coords, valid, nbuf, H, W);
+}
+
+void launch_reproject_motion(const float* poses, const float* disps, const float* intr, int intr_stride,
+                             const int64_t* ii, const int64_t* jj, const float* target, int E, int nbuf, int H,
+                             int W, float* coords, float* valid, float* motn, hipStream_t s) {
+  hipLaunchKernelGGL(reproject_motion_kernel, dim3((H * W + 255) / 256, E), dim3(256), 0, s, poses, disps, intr,
+                     intr_stride, ii, jj, target, coords, valid, motn, nbuf, H, W);
 }
 
 void launch_iproj(const float* poses, const float* disps, const float* intr, int nm, int H, int W,

@@ -19,7 +19,7 @@ from ._lib import DroidBackendError  # noqa: F401
 
 __all__ = ["ba", "frame_distance", "projmap", "depth_filter", "iproj", "altcorr_forward",
            "altcorr_backward", "corr_index_forward", "corr_index_backward",
-           "altcorr_pyramid_forward"]  # the last one is an addition
+           "altcorr_pyramid_forward", "reproject", "motion_features"]  # the last three are additions
 
 _DT = {torch.float16: _lib.DROID_F16, torch.float32: _lib.DROID_F32, torch.float64: _lib.DROID_F64}
 _workspaces = {}
@@ -154,6 +154,55 @@ def projmap(poses, disps, intrinsics, ii, jj):
                                  jj.data_ptr(), E, nbuf, H, W, coords.data_ptr(), valid.data_ptr(),
                                  _stream()), "projmap")
     return [coords, valid]
+
+
+def reproject(poses, disps, intrinsics, ii, jj, target=None):
+    """`DepthVideo.reproject` (droid_slam/depth_video.py:150-158 -> geom/projective_ops.py:96-125) without
+    lietorch: coords [1,E,H,W,2], valid [1,E,H,W,1] for the edges ii -> jj; stereo edges (ii == jj) use the fixed
+    baseline.  `intrinsics` is [nbuf,4] (per frame, as `video.intrinsics`) or [4].  With `target` [1,E,H,W,2]
+    (or [E,H,W,2]) the motion features of factor_graph.py:203-205 are produced in the same pass and returned as
+    a third tensor [1,E,4,H,W]."""
+    lib = _lib.load()
+    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
+        _check_input(x, n)
+    if ii.dtype != torch.int64 or jj.dtype != torch.int64:
+        raise RuntimeError("ii and jj must be int64")
+    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics")) + (((target, "target"),) if target is not None else ()):
+        if x.dtype != torch.float32:
+            raise RuntimeError(f"{n} must be float32")
+    if poses.dim() == 3:  # accept the batched [1,nbuf,...] tensors the caller holds
+        poses, disps = poses[0], disps[0]
+        if intrinsics.dim() == 3:
+            intrinsics = intrinsics[0]
+    poses, disps, intrinsics = poses.contiguous(), disps.contiguous(), intrinsics.contiguous()
+    ii, jj = ii.reshape(-1).contiguous(), jj.reshape(-1).contiguous()
+    nbuf, H, W = disps.shape
+    nbuf = min(int(nbuf), int(poses.shape[0]))
+    stride = 4 if intrinsics.dim() == 2 else 0
+    if stride == 4 and int(intrinsics.shape[0]) < nbuf:
+        raise ValueError("reproject: intrinsics has fewer rows than frames")
+    E = int(ii.shape[0])
+    coords = torch.empty((1, E, H, W, 2), dtype=torch.float32, device=poses.device)
+    valid = torch.empty((1, E, H, W, 1), dtype=torch.float32, device=poses.device)
+    motn = None
+    tptr = None
+    if target is not None:
+        _check_input(target, "target")
+        target = target.reshape(E, H, W, 2).contiguous()
+        motn = torch.empty((1, E, 4, H, W), dtype=torch.float32, device=poses.device)
+        tptr = target.data_ptr()
+    _lib.check(lib.droid_reproject_motion(poses.data_ptr(), disps.data_ptr(), intrinsics.data_ptr(), stride,
+                                          ii.data_ptr(), jj.data_ptr(), tptr, E, nbuf, H, W, coords.data_ptr(),
+                                          valid.data_ptr(), motn.data_ptr() if motn is not None else None,
+                                          _stream()), "reproject")
+    return (coords, valid) if motn is None else (coords, valid, motn)
+
+
+def motion_features(poses, disps, intrinsics, ii, jj, target):
+    """factor_graph.py:203-205 in one call: `coords1, mask = video.reproject(ii, jj);
+    motn = cat([coords1 - coords0, target - coords1], -1).permute(0,1,4,2,3).clamp(-64, 64)` -> (motn, coords1, mask)."""
+    coords, valid, motn = reproject(poses, disps, intrinsics, ii, jj, target)
+    return motn, coords, valid
 
 
 def depth_filter(poses, disps, intrinsics, ix, thresh):

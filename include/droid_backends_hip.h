@@ -170,6 +170,19 @@ int droid_projmap(const float *poses, const float *disps, const float *intrinsic
                   const int64_t *ii, const int64_t *jj, int E, int nbuf, int H, int W,
                   float *coords, float *valid, void *stream);
 
+/* reproject + motion features: what `DepthVideo.reproject` and the three lines after
+ * it compute for every update-operator call, in one pass and without lietorch --
+ *   droid_slam/depth_video.py:150-158 -> geom/projective_ops.py:96-125 (`projective_transform`: source-frame
+ *   intrinsics for the back-projection, target-frame intrinsics for the projection, stereo edges ii == jj use the
+ *   baseline (-0.1,0,0), depth < 0.1 projects with depth 1, valid = depth > 0.2), factor_graph.py:203-205
+ *   (`motn = cat(coords1 - coords0, target - coords1).permute(0,1,4,2,3).clamp(-64, 64)`).
+ * intrinsics: [nbuf,4] with intr_stride = 4, or one [4] for all frames with intr_stride = 0.
+ * target [E,H,W,2] f32 and motn [E,4,H,W] f32 may both be null (plain reproject).
+ * coords [E,H,W,2] f32, valid [E,H,W,1] f32.  Edges with an index outside [0,nbuf) produce zeros. */
+int droid_reproject_motion(const float *poses, const float *disps, const float *intrinsics, int intr_stride,
+                           const int64_t *ii, const int64_t *jj, const float *target, int E, int nbuf, int H,
+                           int W, float *coords, float *valid, float *motn, void *stream);
+
 /* iproj (droid.cpp:157-166 -> droid_kernels.cu:779-850, :1518-1541): points [nm,H,W,3] f32 */
 int droid_iproj(const float *poses, const float *disps, const float *intrinsics, int nm, int H,
                 int W, float *points, void *stream);

@@ -67,3 +67,54 @@ def test_depth_filter_counts_consistent_neighbours(backends, prob):
     cnt = backends.depth_filter(poses, disps, intr, ix, thresh).cpu().numpy()
     assert cnt.shape == (2, 48, 64)
     assert cnt.max() <= 6 and cnt[:, 8:-8, 8:-8].mean() > 3.0
+
+
+def _reproject_case(prob, rng, per_frame_K):
+    poses = prob.poses.copy()
+    poses[5, :3] += np.array([0, 0, -6.0], np.float32)      # some edges end behind the camera
+    nb = prob.disps.shape[0]
+    st = np.array([2, nb - 1, nb // 2])
+    ii = np.concatenate([prob.ii, st])                       # + three stereo edges (ii == jj)
+    jj = np.concatenate([prob.jj, st])
+    K = prob.intrinsics.astype(np.float32)
+    if per_frame_K:
+        K = np.stack([K * np.float32(1.0 + 0.01 * (f % 7)) for f in range(prob.disps.shape[0])]).astype(np.float32)
+    H, W = prob.disps.shape[1:]
+    target = rng.uniform(-20, 90, (len(ii), H, W, 2)).astype(np.float32)
+    return poses, ii, jj, K, target
+
+
+@pytest.mark.parametrize("per_frame_K", [False, True])
+def test_reproject_and_motion_features(backends, prob, per_frame_K):
+    """Fused DepthVideo.reproject + motion features against the numpy restatement: coordinates
+    within 2e-3 px (fp32 projection), validity identical except on the depth threshold, features clamped to 64."""
+    torch = _torch()
+    from oracle import geom
+    rng = np.random.default_rng(11)
+    poses, ii, jj, K, target = _reproject_case(prob, rng, per_frame_K)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    c, v, m = backends.reproject(t(poses), t(prob.disps), t(K), t(ii), t(jj), t(target))
+    rm, rc, rv = geom.motion_features(poses, prob.disps, K, ii, jj, target)
+    c, v, m = c.cpu().numpy()[0], v.cpu().numpy()[0], m.cpu().numpy()[0]
+    assert c.shape == rc.shape and v.shape == rv.shape and m.shape == rm.shape
+    ok = np.abs(rc).max(axis=-1) < 1e4                       # pixels near the depth clamp blow up in both
+    assert np.abs(c - rc)[ok].max() < 2e-3 * max(1.0, np.abs(rc[ok]).max() / 100)
+    assert np.mean(v != rv) < 1e-4
+    assert np.abs(m - rm).max() < 5e-3 and np.abs(m).max() <= 64.0
+    assert (rv == 0).any() and (np.abs(rm) == 64.0).any()    # the case exercises both branches
+    # plain reproject (no target) returns the same coordinates; motion_features() orders (motn, coords, mask)
+    c2, v2 = backends.reproject(t(poses)[None], t(prob.disps)[None], t(K)[None] if per_frame_K else t(K), t(ii), t(jj))
+    assert torch.equal(c2.cpu(), torch.from_numpy(c)[None]) and torch.equal(v2.cpu(), torch.from_numpy(v)[None])
+    m3, c3, _ = backends.motion_features(t(poses), t(prob.disps), t(K), t(ii), t(jj), t(target)[None])
+    assert torch.equal(m3.cpu(), torch.from_numpy(m)[None]) and torch.equal(c3.cpu(), torch.from_numpy(c)[None])
+
+
+def test_reproject_rejects_cpu_tensors_and_bad_indices(backends, prob):
+    torch = _torch()
+    d = to_dev(prob, torch)
+    with pytest.raises(RuntimeError):
+        backends.reproject(torch.from_numpy(prob.poses), d["disps"], d["intrinsics"], d["ii"], d["jj"])
+    ii = d["ii"].clone()
+    ii[0] = 10 ** 6
+    c, v = backends.reproject(d["poses"], d["disps"], d["intrinsics"], ii, d["jj"])
+    assert float(c[0, 0].abs().max()) == 0.0 and float(v[0, 0].max()) == 0.0   # out-of-range edge: zeros, no fault
