@@ -20,9 +20,11 @@ __host__ __device__ inline size_t chol_tiles(int n) {
   const int nb = (n + CHOL_NB - 1) / CHOL_NB, nrb = (n + 1 + CHOL_NB - 1) / CHOL_NB;
   return (size_t)chol_tile_index(nrb, nb, nb);  // = sum_{j<nb} (nrb - j)
 }
-// `ldiag` scratch: [nb] factored diagonal tiles, then [chol_tiles] 64x64 slots `lfin` for the final panel tiles as
+// `ldiag` scratch: [nb] factored diagonal tiles, [nb] tiles M_j, then [chol_tiles] 64x64 slots `lfin` for the final panel tiles as
 // the panel chain hands them over (data-tagged: preset to 0xFF bytes, a strip is there when its bytes are not)
-__host__ __device__ inline size_t chol_lfin_offset(int n) { return ((size_t)(n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
+// then [nb] tiles M_j = L[j+1,j] L_jj^-1 (the back-substitution multiplies by them instead of solving), then lfin
+__host__ __device__ inline size_t chol_mbuf_offset(int n) { return ((size_t)(n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
+__host__ __device__ inline size_t chol_lfin_offset(int n) { return 2 * chol_mbuf_offset(n); }
 __host__ __device__ inline size_t chol_ldiag_doubles(int n) { return chol_lfin_offset(n) + chol_tiles(n) * CHOL_NB * CHOL_NB; }
 
 enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4, HDR_WORDS = 16 };

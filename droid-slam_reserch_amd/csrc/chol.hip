@@ -206,6 +206,22 @@ __device__ __attribute__((noinline)) void wave_gemm_nt16(lds_f64* Cl, const lds_
   }
 }
 
+// C(16x16) = or -= A(16x16) * B(16x16), B NOT transposed (row pitch ldb).  Same operand mapping as above with the
+// B operand read down its columns.  Only used off the pivot chain (M = X L^-1 after the tile is solved).
+template <bool ASSIGN>
+__device__ __attribute__((noinline)) void wave_gemm_nn16(lds_f64* C, const lds_f64* A, const lds_f64* B, int ldb) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 16; k += 4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[r * LDP + k + g], B[(k + g) * ldb + r], acc, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    lds_f64* c = &C[(g + 4 * i) * LDP + r];
+    *c = ASSIGN ? acc[i] : *c - acc[i];
+  }
+}
+
 // In-register Cholesky of the 16x16 block at Lb (LDS, pitch LDP) by one wave.  Lane l < 16 holds
 // row l of the block; lanes 16..31 hold the rows of the identity.  The factorisation is a chain
 // of column operations (scale column j, subtract multiples of it from the later columns) whose
@@ -698,6 +714,32 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
     if (p == 0) STAMP(7);
   }
   STAMP(8);
+  if (PERSIST && bi == kp + 1 && kp + 1 < (n + NB - 1) / NB) {
+    // The tile right below the diagonal also leaves M = X L_kk^-1 (X = the solved tile L[kp+1,kp]) for the
+    // back-substitution, which then multiplies by M^T instead of solving with L_kk^T on its critical chain:
+    // M_q = (X_q - sum_{s>q} M_s L_sq) L_qq^-1, 16-column blocks right to left, in place; each wave owns 16 rows,
+    // so the waves do not have to synchronise.  Off the factorisation's chain (the strips are out already).
+    __syncthreads();  // wave 4 has read the last strip out of BT
+    if (wave < 4) {
+      const int g = wave;
+#pragma unroll 1
+      for (int q = 3; q >= 0; q--) {
+#pragma unroll 1
+        for (int s2 = q + 1; s2 < 4; s2++)
+          wave_gemm_nn16<false>(&BT[(16 * g) * LDP + 16 * q], &BT[(16 * g) * LDP + 16 * s2], &B2[(16 * s2) * LDP + 16 * q], LDP);
+        wave_gemm_nn16<true>(&BT[(16 * g) * LDP + 16 * q], &BT[(16 * g) * LDP + 16 * q], &Wl[256 * q], 16);
+      }
+      gbl_f64* Mj = Ldiag + chol_mbuf_offset(n) + (size_t)kp * NB * NB;
+#pragma unroll
+      for (int it = 0; it < 8; it++) {  // 16 rows x 64 columns of this wave; rows at or beyond n (the rhs row) are zero
+        const int u = it * 64 + lane;
+        const int i = 16 * g + (u >> 5), j2 = (u & 31) * 2;
+        f64x2 v = *(const lds_f64x2*)&BT[i * LDP + j2];
+        if (r0 + i >= n) v = (f64x2){0.0, 0.0};
+        *(gbl_f64x2*)&Mj[i * NB + j2] = v;
+      }
+    }
+  }
   if (PERSIST && diag) {
     // the inverses of the four 16x16 diagonal blocks ride along in the unused upper blocks (0,1) (0,2) (0,3)
     // (1,2) of the side-buffer tile: the backward substitution solves each 16-unknown block with them as one
@@ -960,7 +1002,16 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
   else load_tile64(DROID_LDS(Ld), (const gbl_f64*)S, ld, c0, c0, c0, c0 + wj, c0 + wj, true, 1.0);
   double z = (t < wj) ? S[(size_t)n * ld + c0 + t] : 0.0;  // wave 0 owns z
   int cur = 0;
-  if (j < nb - 1 && t >= 64) load_tile64_w123(DROID_LDS(Tt[0]), (const gbl_f64*)S, ld, (nb - 1) * NB, c0, n, c0 + wj);
+  // tile of block row k in this block column; FAST: for k = j+1 the factorisation left M = L[j+1,j] L_jj^-1, which
+  // is applied AFTER the diagonal solve (x_j = L_jj^-T z' - M^T x_{j+1}): the solve runs while x_{j+1} is still on
+  // its way and only one mat-vec follows its arrival
+  auto load_k = [&](double* dst, int k) {
+    if (FAST && k == j + 1)
+      load_tile64_w123(DROID_LDS(dst), (const gbl_f64*)Ldiag + chol_mbuf_offset(n) + (size_t)j * NB * NB, NB, 0, 0, NB, NB);
+    else
+      load_tile64_w123(DROID_LDS(dst), (const gbl_f64*)S, ld, k * NB, c0, n, c0 + wj);
+  };
+  if (j < nb - 1 && t >= 64) load_k(Tt[0], nb - 1);
   __syncthreads();
   double Lcol[NB];  // wave 0: column t of the diagonal tile (rows above the diagonal read 0)
   double Wcol[16];  // single-launch factor: column (t & 15) of the inverse of this lane's 16x16 diagonal block
@@ -974,9 +1025,41 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
       for (int c = 0; c < 16; c++) Wcol[c] = Wg[c * NB];  // (L_pp^-1)[c][t & 15]
     }
   }
-  for (int k = nb - 1; k > j; k--) {
+  // poll x_k element-wise (lanes beyond the matrix take 0) and return  sum_r Tc[r] x_k[r]  for this lane's column
+  auto poll_matvec = [&](int k, const double (&Tc)[NB]) -> double {
+    const int gi = k * NB + t;
+    double xv = 0.0;
+    if (gi < n) {
+      int spins = 0;
+      while (true) {
+        xv = __hip_atomic_load(&x[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__double_as_longlong(xv) != BSP_SENTINEL) break;
+        if (++spins > (1 << 22)) {  // cannot happen with a resident grid; never hang the GPU
+          dead = 1;
+          atomicExch(err, 1);
+          xv = 0.0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    if (k == j + 1) BSTAMP(1);
+    xk[t] = xv;  // same wave writes and reads: LDS operations of one wave are ordered
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NB; r += 4) {  // x_k in 16-byte broadcast reads against the preloaded column
+      const f64x2 x01 = *(const lds_f64x2*)&DROID_LDS(xk)[r], x23 = *(const lds_f64x2*)&DROID_LDS(xk)[r + 2];
+      a0 = fma(Tc[r + 0], x01[0], a0);
+      a1 = fma(Tc[r + 1], x01[1], a1);
+      a2 = fma(Tc[r + 2], x23[0], a2);
+      a3 = fma(Tc[r + 3], x23[1], a3);
+    }
+    return (a0 + a1) + (a2 + a3);
+  };
+  const int klast = FAST ? j + 2 : j + 1;  // FAST: the tile of block row j+1 (as M) comes after the diagonal solve
+  for (int k = nb - 1; k >= klast; k--) {
     if (t >= 64) {
-      if (k - 1 > j) load_tile64_w123(DROID_LDS(Tt[cur ^ 1]), (const gbl_f64*)S, ld, (k - 1) * NB, c0, n, c0 + wj);
+      if (k - 1 > j) load_k(Tt[cur ^ 1], k - 1);
     } else {
       // column t of the tile (it landed before the last barrier) goes to registers BEFORE the poll: once x_k is
       // there, the mat-vec is 32 broadcast reads and 64 FMAs (it was a rolled loop paying the LDS latency 16 times)
@@ -986,38 +1069,10 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
 #pragma unroll
         for (int r = 0; r < NB; r++) Tc[r] = T[r * LDP + t];
       }
-      // poll this lane's element of x_k (lanes beyond the matrix take 0)
-      const int gi = k * NB + t;
-      double xv = 0.0;
-      if (gi < n) {
-        int spins = 0;
-        while (true) {
-          xv = __hip_atomic_load(&x[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (__double_as_longlong(xv) != BSP_SENTINEL) break;
-          if (++spins > (1 << 22)) {  // cannot happen with a resident grid; never hang the GPU
-            dead = 1;
-            atomicExch(err, 1);
-            xv = 0.0;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      if (k == j + 1) BSTAMP(1);
-      xk[t] = xv;  // same wave writes and reads: LDS operations of one wave are ordered
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-      for (int r = 0; r < NB; r += 4) {  // x_k in 16-byte broadcast reads against the preloaded column
-        const f64x2 x01 = *(const lds_f64x2*)&DROID_LDS(xk)[r], x23 = *(const lds_f64x2*)&DROID_LDS(xk)[r + 2];
-        a0 = fma(Tc[r + 0], x01[0], a0);
-        a1 = fma(Tc[r + 1], x01[1], a1);
-        a2 = fma(Tc[r + 2], x23[0], a2);
-        a3 = fma(Tc[r + 3], x23[1], a3);
-      }
-      z -= (a0 + a1) + (a2 + a3);
+      z -= poll_matvec(k, Tc);
     }
     cur ^= 1;
-    if (k == j + 1) {
+    if (!FAST && k == j + 1) {
       BSTAMP(2);
       break;  // nothing left to prefetch: wave 0 goes straight into the diagonal solve
     }
@@ -1032,6 +1087,12 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
     // solved inside its own 16-lane row with DPP broadcasts, and the rows above receive the block
     // through one 16-term update.
     double xsol = 0.0;
+    double Mc[NB];  // FAST: column t of M, in registers before the solve so that nothing but the poll is left after it
+    if (FAST && j < nb - 1) {
+      const double* T = Tt[cur];
+#pragma unroll
+      for (int r = 0; r < NB; r++) Mc[r] = T[r * LDP + t];
+    }
     const double rinv = FAST ? 0.0 : 1.0 / Ld[t * LDP + t];
     const int rr = t & 15, rowb = t >> 4;
 #define DROID_BS_STEP(B, II)                                                                            \
@@ -1080,6 +1141,8 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
 #undef DROID_BS_BLOCK
 #undef DROID_BS_WTERM
 #undef DROID_BS_STEP
+    BSTAMP(2);
+    if (FAST && j < nb - 1) xsol -= poll_matvec(j + 1, Mc);  // x_j = L_jj^-T z' - M^T x_{j+1}
     if (__double_as_longlong(xsol) == BSP_SENTINEL) xsol = __longlong_as_double(0x7ff8000000000000LL);
     BSTAMP(4);
     if (t < wj) __hip_atomic_store(&x[c0 + t], xsol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
