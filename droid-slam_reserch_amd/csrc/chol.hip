@@ -206,22 +206,6 @@ __device__ __attribute__((noinline)) void wave_gemm_nt16(lds_f64* Cl, const lds_
   }
 }
 
-// C(16x16) = or -= A(16x16) * B(16x16), B NOT transposed (row pitch ldb).  Same operand mapping as above with the
-// B operand read down its columns.  Only used off the pivot chain (M = X L^-1 after the tile is solved).
-template <bool ASSIGN>
-__device__ __attribute__((noinline)) void wave_gemm_nn16(lds_f64* C, const lds_f64* A, const lds_f64* B, int ldb) {
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int k = 0; k < 16; k += 4)
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[r * LDP + k + g], B[(k + g) * ldb + r], acc, 0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    lds_f64* c = &C[(g + 4 * i) * LDP + r];
-    *c = ASSIGN ? acc[i] : *c - acc[i];
-  }
-}
-
 // In-register Cholesky of the 16x16 block at Lb (LDS, pitch LDP) by one wave.  Lane l < 16 holds
 // row l of the block; lanes 16..31 hold the rows of the identity.  The factorisation is a chain
 // of column operations (scale column j, subtract multiples of it from the later columns) whose
@@ -722,12 +706,26 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
     __syncthreads();  // wave 4 has read the last strip out of BT
     if (wave < 4) {
       const int g = wave;
-#pragma unroll 1
+#pragma unroll
       for (int q = 3; q >= 0; q--) {
-#pragma unroll 1
-        for (int s2 = q + 1; s2 < 4; s2++)
-          wave_gemm_nn16<false>(&BT[(16 * g) * LDP + 16 * q], &BT[(16 * g) * LDP + 16 * s2], &B2[(16 * s2) * LDP + 16 * q], LDP);
-        wave_gemm_nn16<true>(&BT[(16 * g) * LDP + 16 * q], &BT[(16 * g) * LDP + 16 * q], &Wl[256 * q], 16);
+        lds_f64* Cq = &BT[(16 * g) * LDP + 16 * q];
+        f64x4 acc;
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = Cq[(fg + 4 * i) * LDP + fr];
+#pragma unroll
+        for (int s2 = q + 1; s2 < 4; s2++)  // acc -= M_s L_sq (B operand read down the columns of the L block)
+#pragma unroll
+          for (int kk = 0; kk < 16; kk += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-BT[(16 * g + fr) * LDP + 16 * s2 + kk + fg],
+                                                       B2[(16 * s2 + kk + fg) * LDP + 16 * q + fr], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) Cq[(fg + 4 * i) * LDP + fr] = acc[i];  // back through LDS into the A-operand layout
+        f64x4 m = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4)  // M_q = acc * L_qq^-1
+          m = __builtin_amdgcn_mfma_f64_16x16x4f64(Cq[fr * LDP + kk + fg], Wl[256 * q + (kk + fg) * 16 + fr], m, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) Cq[(fg + 4 * i) * LDP + fr] = m[i];
       }
       gbl_f64* Mj = Ldiag + chol_mbuf_offset(n) + (size_t)kp * NB * NB;
 #pragma unroll
