@@ -39,12 +39,22 @@ def test_host_side_argument_checks_need_no_gpu(backends):
     rc = lib.droid_ba(None, None, None, None, None, None, None, None, None, 4, 8, 8, 8, 8, 5, 3, 1, 1e-4, 0.1, 0,
                       None, None, None, 0, None)  # t1 <= t0
     assert rc == -1 and b"window" in lib.droid_last_error()
+    rc = lib.droid_reproject_motion(None, None, None, 3, None, None, None, 4, 8, 8, 8, None, None, None, None)  # bad stride
+    assert rc == -1 and b"reproject_motion" in lib.droid_last_error()
+    assert lib.droid_reproject_motion(None, None, None, 4, None, None, None, 0, 8, 8, 8, None, None, None, None) == 0  # E = 0
+    assert lib.droid_chol_scratch_doubles(0) == 0
+    n = 1530   # system rows of 128 bytes + diagonal / M tiles + one hand-over slot per lower-triangle tile + flags
+    assert lib.droid_chol_scratch_doubles(n) >= (n + 1) * 1536 + (2 * 24 + 300) * 4096
 
 
 def test_python_mirror_has_the_reference_operators(backends):
     for name in ["ba", "frame_distance", "projmap", "depth_filter", "iproj", "altcorr_forward",
                  "altcorr_backward", "corr_index_forward", "corr_index_backward"]:
         assert callable(getattr(backends, name))
+    for name in ["altcorr_pyramid_forward", "reproject", "motion_features"]:   # additions
+        assert callable(getattr(backends, name))
+    from droid_backends import keyframes
+    assert callable(keyframes.load) and callable(keyframes.save)
 
 
 def test_cpu_tensors_are_refused_not_emulated(backends):
