@@ -4,20 +4,23 @@
 // /root/reference/src/droid_kernels.cu:1192-1213): same damping `diag += ep + lm*diag` (:1197),
 // same fp64 LL^T factorisation of the same matrix, failure => caller zeroes dx (:1207-1210).
 //
-// Layout: S is (n+1) x ld row-major, ld = n+1 rounded up to a multiple of 8 (64-byte rows); the
-// lower triangle of S[0:n,0:n] is the matrix, row n holds the right-hand side.  Factoring the augmented matrix turns row n into
-// y^T = (L^-1 b)^T for free (the forward substitution rides along with the panel TRSM), so only
+// Layout: S is (n+1) x ld row-major, ld = n+1 rounded up to a multiple of 16 (128-byte rows); the
+// lower triangle of S[0:n,0:n] is the matrix, row n holds the right-hand side.  Factoring the augmented matrix
+// turns row n into y^T = (L^-1 b)^T for free (the forward substitution rides along with the panel TRSM), so only
 // the backward substitution L^T x = y remains.
 //
 // The solve is a latency chain (n = 6P sequential pivots), not a flop problem, so the design
 // minimises the dependent path per pivot:
-//   * blocked right-looking factorisation, NB = 64, two launches per block column;
-//   * panel kernel: every row block re-factors the 64x64 diagonal block in LDS (cheaper than a
-//     grid-wide hand-off) as 4 steps of {16x16 in-register wave factorisation with
-//     readlane-broadcast pivots and an rsqrt+Newton pivot reciprocal (no fp64 sqrt/div on the
-//     chain), row-parallel 16-wide triangular solve, v_mfma_f64_16x16x4 block updates}, then
-//     solves its own 64 rows against it the same way;
-//   * update kernel: A22 -= L21 L21^T, one 64x64 tile per workgroup on v_mfma_f64_16x16x4.
+//   * blocked right-looking factorisation, NB = 64.  One 512-thread workgroup handles one 64x64 tile of one
+//     block-column step (`chol_tile`): trailing tiles get their rank-64 update on v_mfma_f64_16x16x4; tiles of the
+//     next block column additionally re-factor the diagonal tile in LDS (redundantly, cheaper than a hand-off
+//     inside the step) as 4 steps of {16x16 in-register wave factorisation with DPP-broadcast multipliers and an
+//     rsqrt+Newton pivot reciprocal, triangular solves as GEMMs with the block inverse, MFMA block updates} and
+//     solve their own tile against it;
+//   * `chol_factor_persistent_kernel`: the whole factorisation in ONE launch of a co-resident grid (static tile
+//     ownership, hand-off flags for trailing tiles, data-tagged 16-column strips for the panel chain);
+//     `chol_step_kernel` (one launch per block column, same body) is the fallback;
+//   * `chol_backsolve_persistent_kernel`: the backward substitution in one launch, x itself is the hand-off flag.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
