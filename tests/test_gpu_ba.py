@@ -236,3 +236,32 @@ def test_ba_golden_vectors_on_device(backends, synth):
         hip = run_hip_ba(backends, p, torch, 2)
         assert np.abs(hip["poses"] - g[f"{name}_poses"]).max() < TOL
         assert np.abs(hip["disps"] - g[f"{name}_disps"]).max() < TOL
+
+
+def test_chol_single_launch_stress(backends):
+    """The single-launch factorisation and back-substitution hand data between workgroups through flags and
+    data-tagged slots: repeat the solve many times on varying sizes and check every result (a lost or stale
+    hand-off shows up as a wrong solution or a raised failure flag)."""
+    torch = _torch()
+    lib = backends._lib.load()
+    rng = np.random.default_rng(123)
+    s = torch.cuda.current_stream().cuda_stream
+    cases = []
+    for n in (1530, 1531, 1600, 897, 642, 1288):
+        B = rng.normal(size=(n, n // 2))
+        A = B @ B.T + n * 0.05 * np.eye(n)
+        b = rng.normal(size=n)
+        cases.append((n, A, np.linalg.solve(A, b), torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda(),
+                      torch.zeros(lib.droid_chol_scratch_doubles(n), dtype=torch.float64, device="cuda")))
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    worst = 0.0
+    for rep in range(40):
+        for n, A, ref, dA, db, scratch in cases:
+            x = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+            lib.droid_chol_solve(dA.data_ptr(), db.data_ptr(), x.data_ptr(), n, scratch.data_ptr(), flag.data_ptr(), s)
+            got = x.cpu().numpy()   # synchronises
+            assert int(flag.item()) == 0, (rep, n)
+            err = np.abs(got - ref).max() / np.abs(ref).max()
+            worst = max(worst, err)
+            assert err < 1e-9, (rep, n, err)
+    print(f"240 solves, worst relative error {worst:.2e}")
