@@ -218,6 +218,14 @@ def bench_corr(args, rank, world, dev, prob):
                                    hbm_gbs=Ea * H * W * 40.0 / ms_rp / 1e6,
                                    frac_of_8TBs=Ea * H * W * 40.0 / ms_rp / 1e6 / HBM_PEAK_GBS,
                                    kernel="reproject_motion_kernel")
+    # frame_distance over ALL ordered pairs of the 256 keyframes (depth_video.py:160-190 with ii=None: the
+    # proximity matrix of the global backend), one launch
+    Nk = prob.disps.shape[0]
+    gi, gj = torch.meshgrid(torch.arange(Nk, device=dev), torch.arange(Nk, device=dev), indexing="ij")
+    gi, gj = gi.reshape(-1).contiguous(), gj.reshape(-1).contiguous()
+    ms_fd = timeit(lambda: db.frame_distance(pz, dz, kz, gi, gj, 0.3), 3)
+    out["frame_distance_all_pairs"] = dict(pairs=int(gi.numel()), ms=ms_fd, gpix_per_s=gi.numel() * H * W / ms_fd / 1e6,
+                                           kernel="frame_distance_kernel, 65536 pairs x 3072 pixels")
     return out
 
 
