@@ -1171,8 +1171,11 @@ static int chol_resident_workgroups() {
 static bool chol_single_launch(const double* sys, int n, int ld, const int* flags, const double* ldiag) {
   static const bool off = (getenv("DROID_CHOL_MULTI_LAUNCH") != nullptr);  // diagnostics: the per-step path
   const int nb = (n + NB - 1) / NB;
+  // beyond ~10 tiles per resident workgroup (n ~ 4400 on 256 CUs) the trailing updates, serialised inside the
+  // persistent workgroups, outweigh the saved kernel boundaries (measured cross-over: n = 4500)
   return !off && flags != nullptr && ldiag != nullptr && nb >= 2 && (ld % 16) == 0 &&
-         (reinterpret_cast<uintptr_t>(sys) % 128) == 0 && chol_resident_workgroups() >= 8;
+         (reinterpret_cast<uintptr_t>(sys) % 128) == 0 && chol_resident_workgroups() >= 8 &&
+         chol_tiles(n) <= (size_t)10 * chol_resident_workgroups();
 }
 
 void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag, int* flags,
