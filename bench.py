@@ -226,6 +226,16 @@ def bench_corr(args, rank, world, dev, prob):
     ms_fd = timeit(lambda: db.frame_distance(pz, dz, kz, gi, gj, 0.3), 3)
     out["frame_distance_all_pairs"] = dict(pairs=int(gi.numel()), ms=ms_fd, gpix_per_s=gi.numel() * H * W / ms_fd / 1e6,
                                            kernel="frame_distance_kernel, 65536 pairs x 3072 pixels")
+    # the two training-only operators (modules/corr.py:15-20, :82-88), level 0, a smaller batch: scatter-adds
+    Bb = min(B, 32)
+    vb, cb = pyramid[0][:Bb].contiguous(), cl[0][:Bb].contiguous()
+    gv = torch.randn_like(db.corr_index_forward(vb, cb, r)[0])
+    ms_cb = timeit(lambda: db.corr_index_backward(vb, cb, gv, r), 3)
+    out["corr_index_backward_fp16_level0"] = dict(gpix_per_s=Bb * H * W / ms_cb / 1e6, ms=ms_cb, edges=Bb)
+    f1b, f2b, cab = a1[:Bb].contiguous(), a2[0][:Bb].contiguous(), ca[0][:Bb].contiguous()
+    ga = torch.randn_like(db.altcorr_forward(f1b, f2b, cab, r)[0])
+    ms_ab = timeit(lambda: db.altcorr_backward(f1b, f2b, cab, ga, r), 3)
+    out["altcorr_backward_fp32_level0"] = dict(gpix_per_s=Bb * H * W / ms_ab / 1e6, ms=ms_ab, edges=Bb)
     return out
 
 

@@ -1136,6 +1136,13 @@ __global__ __launch_bounds__(256) void altcorr_backward_kernel(
   const float* f1 = fmap1 + ((size_t)b * H1W1 + q) * C;
   float* g1 = fmap1_grad + ((size_t)b * H1W1 + q) * C;
   const float* cg = corr_grad + (((size_t)b * N + n) * rd * rd) * H1W1 + q;
+  // the query's own feature gradient is summed in registers over all taps (one atomic per channel at the end,
+  // not one per tap and channel); channels c = sub + 16 m, at most 16 of them per thread (C <= 256), else atomics
+  constexpr int G1MAX = 16;
+  const bool g1_regs = C <= 16 * G1MAX;
+  float acc1[G1MAX];
+#pragma unroll
+  for (int m = 0; m < G1MAX; m++) acc1[m] = 0.f;
   for (int iy = 0; iy < rd + 1; iy++)
     for (int ix = 0; ix < rd + 1; ix++) {
       const int h2 = bl.y1 + iy, w2 = bl.x1 + ix;
@@ -1147,11 +1154,29 @@ __global__ __launch_bounds__(256) void altcorr_backward_kernel(
       if (iy < rd && ix < rd) g += cg[(size_t)(iy + rd * ix) * H1W1] * ((1.f - bl.dy) * (1.f - bl.dx));
       const float* f2 = fmap2 + (((size_t)b * H2 + h2) * W2 + w2) * C;
       float* g2 = fmap2_grad + (((size_t)b * H2 + h2) * W2 + w2) * C;
-      for (int c = sub; c < C; c += 16) {
-        atomicAdd(&g1[c], g * f2[c]);
-        atomicAdd(&g2[c], g * f1[c]);
+      if (g1_regs) {
+#pragma unroll
+        for (int m = 0; m < G1MAX; m++) {
+          const int c = sub + 16 * m;
+          if (c < C) {
+            acc1[m] += g * f2[c];
+            atomicAdd(&g2[c], g * f1[c]);
+          }
+        }
+      } else {
+        for (int c = sub; c < C; c += 16) {
+          atomicAdd(&g1[c], g * f2[c]);
+          atomicAdd(&g2[c], g * f1[c]);
+        }
       }
     }
+  if (g1_regs) {
+#pragma unroll
+    for (int m = 0; m < G1MAX; m++) {
+      const int c = sub + 16 * m;
+      if (c < C) atomicAdd(&g1[c], acc1[m]);
+    }
+  }
 }
 
 int launch_altcorr_backward(const float* f1, const float* f2, const float* coords,
