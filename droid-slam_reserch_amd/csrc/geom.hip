@@ -84,7 +84,12 @@ __global__ __launch_bounds__(256) void projmap_kernel(
   const int HW = H * W;
   if (k >= HW) return;
   const int64_t i64 = ii[e], j64 = jj[e];
-  if (i64 < 0 || i64 >= nbuf || j64 < 0 || j64 >= nbuf) return;
+  if (i64 < 0 || i64 >= nbuf || j64 < 0 || j64 >= nbuf) {  // edge with a bad index: zeros, no fault
+    float* c = coords + ((size_t)e * HW + k) * 3;
+    c[0] = c[1] = c[2] = 0.f;
+    valid[(size_t)e * HW + k] = 0.f;
+    return;
+  }
   const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
   const Rel T = rel_pose_plain(poses, (int)i64, (int)j64);
   const float u = (float)(k % W), v = (float)(k / W);
@@ -227,8 +232,6 @@ void launch_frame_distance(const float* poses, const float* disps, const float* 
 void launch_projmap(const float* poses, const float* disps, const float* intr, const int64_t* ii,
                     const int64_t* jj, int E, int nbuf, int H, int W, float* coords, float* valid,
                     hipStream_t s) {
-  (void)hipMemsetAsync(coords, 0, sizeof(float) * (size_t)E * H * W * 3, s);
-  (void)hipMemsetAsync(valid, 0, sizeof(float) * (size_t)E * H * W, s);
   hipLaunchKernelGGL(projmap_kernel, dim3((H * W + 255) / 256, E), dim3(256), 0, s, poses, disps,
                      intr, ii, jj, coords, valid, nbuf, H, W);
 }
