@@ -655,9 +655,12 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
           else gstore<true>(gp, v[0]);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) cfp_store(&done[bi], 4 * kp + p);
-      if (p == 3) STAMP(9);
+      // trailing tiles and the back-substitution read the matrix copy only when the whole tile is out: one
+      // acknowledgement wait and one flag, after the last strip (the panel chain polls the hand-over slot instead)
+      if (p == 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) cfp_store(&done[bi], 4 * kp + 3);
+      }
     }
     if (p == 3) break;
     const int q = p + 1;
@@ -667,16 +670,17 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
       wave_potrf16(&B2[(16 * q) * LDP + 16 * q], &Wl[256 * q], Idn, fail, diag);
       if (p == 0) STAMP(6);
     } else {
-      // the other rank-16 updates of the diagonal tile, round-robin over the less loaded waves
+      // the other rank-16 updates of the diagonal tile, round-robin over the less loaded waves (not wave 4: it
+      // shares the pivot wave's SIMD and writes the strips out)
       int cnt = 0;
 #pragma unroll 1
       for (int r = q; r < 4; r++)
 #pragma unroll 1
         for (int s2 = q; s2 <= r; s2++) {
           if (r == q && s2 == q) continue;  // wave 0's block
-          {  // waves 1..4 except wave q, which finishes T(0,q) in this slot
-            const int slot = cnt % 3;
-            const int owner = 1 + slot + ((1 + slot >= q) ? 1 : 0);
+          {  // waves 1..3 except wave q, which finishes T(0,q) in this slot
+            const int slot = cnt % 2;
+            const int owner = 1 + slot + ((1 + slot >= q) ? 1 : 0);  // the two of waves 1..3 that are not wave q
             if (owner == wave)
               wave_gemm_nt16<false>(&B2[(16 * r) * LDP + 16 * s2], &B2[(16 * r) * LDP + 16 * p],
                                     &B2[(16 * s2) * LDP + 16 * p], LDP);
