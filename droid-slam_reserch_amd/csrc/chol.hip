@@ -479,10 +479,28 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
     }
     const int p0 = k * NB;
     frag_load_global<2>(acc, S, ld, r0, q0, w4, 2 * grp, nrows, n, bi == bj);
+    if (PERSIST && bj == kp + 1) {
+      // tiles of the NEXT panel column take the two panel tiles strip by strip out of the hand-over slots, like
+      // the panel workgroups do: their update ends right behind the last strip instead of a flag, an
+      // acknowledgement and two whole-tile loads later, so the next step's panel workgroups find their tile ready
+      const int nrb = (nrows + NB - 1) / NB;
+      const gbl_f64* slot0 = Ldiag + chol_lfin_offset(n) + (size_t)chol_tile_index(nrb, bi, k) * NB * NB;
+      const gbl_f64* slot1 = Ldiag + chol_lfin_offset(n) + (size_t)chol_tile_index(nrb, bj, k) * NB * NB;
+      const lds_f64* Bx = (bi == bj) ? B0 : B1;
+      for (int sp = 0; sp < 4; sp++) {
+        if (grp == 0) load_strip64(B0, slot0, r0, sp, r0, nrows, fail, abortf);
+        else if (bi != bj) load_strip64(B1, slot1, q0, sp, q0, n, fail, abortf);
+        __syncthreads();
+#pragma unroll
+        for (int nn = 0; nn < 2; nn++)
+          block_update16(acc[nn], &B0[(16 * w4) * LDP + 16 * sp], &Bx[(16 * (2 * grp + nn)) * LDP + 16 * sp]);
+      }
+    } else {
     if (grp == 0) load_tile64<PERSIST>(B0, S, ld, r0, p0, r0, nrows, p0 + NB, false, 0.0);
     else if (bi != bj) load_tile64<PERSIST>(B1, S, ld, q0, p0, q0, n, p0 + NB, false, 0.0);
     __syncthreads();
     strip_update<2>(acc, B0, (bi == bj) ? B0 : B1, w4, 2 * grp);
+    }
 #pragma unroll
     for (int nn = 0; nn < 2; nn++)
 #pragma unroll
@@ -859,8 +877,9 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
           // version here, the strips are awaited inside the body
           const int* p = nullptr;
           int need = 4 * k + 3;
-          if (t == 0 && !panel) p = &done[bi];
-          else if (t == 1 && !panel && bj != bi) p = &done[bj];
+          const bool flagged = !panel && bj != kp + 1;  // tiles of the next panel column poll the hand-over slots
+          if (t == 0 && flagged) p = &done[bi];
+          else if (t == 1 && flagged && bj != bi) p = &done[bj];
           else if (t == 2 && panel && bi != bj) { p = &dver[bj]; need = k; }
           bool sat = (p == nullptr);
           int spins = 0;
