@@ -588,6 +588,15 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
           }
         }
       }
+      // the deferred columns of the tile to solve take strips 0..2 here, while the waves wait for the producer
+      // anyway; the last strip's share stays in the pivot-block slots (nothing is added in front of the first
+      // pivot block), where it is a quarter of the rank-64 update that used to sit there
+      if (sp < 3) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+          if (i < ndef)
+            block_update16(dacc[i], &B0[(16 * dg) * LDP + 16 * sp], &B1[(16 * ((wave >= 5) ? i + 1 : wave)) * LDP + 16 * sp]);
+      }
     }
   } else {
     __syncthreads();
@@ -710,7 +719,8 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
       const bool mine = (wave >= 5) ? (ndef > 0) : (ndef > 0 && wave == q);
       if (mine) {
         f64x4 acc = dacc[0];
-        if (k >= 0) strip_update_tile(acc, B0, B1, dg, q);
+        if (!PERSIST && k >= 0) strip_update_tile(acc, B0, B1, dg, q);
+        if (PERSIST && k >= 0) block_update16(acc, &B0[(16 * dg) * LDP + 48], &B1[(16 * q) * LDP + 48]);  // last strip only
 #pragma unroll
         for (int pp = 0; pp < 3; pp++)  // unrolled: the operand reads of all blocks are in flight together
           if (pp <= p) block_update16(acc, &BT[(16 * dg) * LDP + 16 * pp], &B2[(16 * q) * LDP + 16 * pp]);
