@@ -588,10 +588,10 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
           }
         }
       }
-      // the deferred columns of the tile to solve take strips 0..2 here, while the waves wait for the producer
-      // anyway; the last strip's share stays in the pivot-block slots (nothing is added in front of the first
-      // pivot block), where it is a quarter of the rank-64 update that used to sit there
-      if (sp < 3) {
+      // the deferred columns of the tile to solve take their rank-16 updates here too: during strips 0..2 the waves
+      // wait for the producer anyway, and the last strip's share (waves 1-3, 5-7) overlaps with the first pivot
+      // block.  Only the left-looking block updates and the solves stay in the pivot-block slots.
+      {
 #pragma unroll
         for (int i = 0; i < 3; i++)
           if (i < ndef)
@@ -720,7 +720,6 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
       if (mine) {
         f64x4 acc = dacc[0];
         if (!PERSIST && k >= 0) strip_update_tile(acc, B0, B1, dg, q);
-        if (PERSIST && k >= 0) block_update16(acc, &B0[(16 * dg) * LDP + 48], &B1[(16 * q) * LDP + 48]);  // last strip only
 #pragma unroll
         for (int pp = 0; pp < 3; pp++)  // unrolled: the operand reads of all blocks are in flight together
           if (pp <= p) block_update16(acc, &BT[(16 * dg) * LDP + 16 * pp], &B2[(16 * q) * LDP + 16 * pp]);
