@@ -808,10 +808,11 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
 //   * static ownership: lower-triangle tiles in column-major order, tile idx -> workgroup
 //     idx % grid; a workgroup applies every step to its own tiles, so a tile's intermediate
 //     versions never change hands (and panel tiles come first in every workgroup's step);
-//   * data flow instead of barriers: done[i] = 4*c + s for the last 16-column strip s of the last final tile
-//     L[i, c] of block row i, dver[j] = trailing updates applied to the diagonal tile (j, j) by its owner
-//     (0 = damped).  A trailing tile (bi, bj) at step k waits for done[bi], done[bj] >= 4k+3; a panel tile
-//     waits for dver[k+1] >= k and then takes the two panel tiles strip by strip as they are published;
+//   * data flow instead of barriers: done[i] = 4*c + 3 once the final tile L[i, c] of block row i is completely
+//     in the matrix, dver[j] = trailing updates applied to the diagonal tile (j, j) by its owner (0 = damped).
+//     A trailing tile (bi, bj) at step k waits for done[bi], done[bj] >= 4k+3; a panel tile waits for
+//     dver[k+1] >= k and then takes the two panel tiles strip by strip out of their data-tagged hand-over slots,
+//     as they are written; so do the trailing tiles of the next panel column (no flag at all);
 //     nothing waits for unrelated trailing tiles (look-ahead comes for free);
 //   * hand-off without cache maintenance: every tile store is written through (sc1), tiles of other
 //     workgroups are read with sc1 loads, the flags likewise: store, s_waitcnt vmcnt(0), barrier, flag |
