@@ -716,7 +716,12 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
   const int pixl = tid & (SF_TP - 1), part = tid >> 6;  // four threads per pixel split the edges
   const int x_beg = v.seg_ptr[m], nedges = v.seg_ptr[m + 1] - x_beg;
   const bool resident = nedges <= SLOT_MAXE;  // the usual case: metadata loaded once
+  // pose index of every Schur entry of the slot for the fold at the end (single-block variant: at most 16 entries):
+  // two dependent global loads per folded element made the fold 15 % of the workgroup's time
+  __shared__ int s_pose[MULTI ? 1 : 17];
+  if (!MULTI && tid < nent) s_pose[tid] = v.ent_pose[e0 + tid];
   if (resident) load_slot_meta(sm, v, poses, jj, f, x_beg, nedges, has_self ? 1 : 0);
+  else __syncthreads();
 
   // software prefetch of the next tile's per-pixel inputs (Q, disparity, the weights of this
   // thread's first four edges): issued before the MFMA phase of the current tile
@@ -914,12 +919,12 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
             const int lj = rb0 + 16 * tb + r;          // B side, always an E row
             if (lj >= R || li > R) continue;
             const double val = -(double)acc[t][x];
-            const int gj = 6 * v.ent_pose[e0 + lj / 6] + lj % 6;
+            const int gj = 6 * (MULTI ? v.ent_pose[e0 + lj / 6] : s_pose[lj / 6]) + lj % 6;
             if (li == R) {  // w row: reduced rhs
               atomicAdd(&v.sys[(size_t)v.n * v.ld + gj], val);
               continue;
             }
-            const int gi = 6 * v.ent_pose[e0 + li / 6] + li % 6;
+            const int gi = 6 * (MULTI ? v.ent_pose[e0 + li / 6] : s_pose[li / 6]) + li % 6;
             const bool diag_tile = (ba == bb) && (ta == tb);
             if (diag_tile) {  // both (li,lj) and (lj,li) are computed
               if (gi >= gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
