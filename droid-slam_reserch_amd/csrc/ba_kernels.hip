@@ -990,6 +990,9 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
   const int R = 6 * nent;  // E rows; row R is the w row, row R+1 the Q row
   const int nedges = v.seg_ptr[m + 1] - v.seg_ptr[m];
   if (schur_class(R + 1, nedges, 1) != CLS) return;
+  // pose index of every entry, for the fold (6 rows per entry; dependent global loads per folded element otherwise)
+  __shared__ int s_pose[(ROWS + 5) / 6 + 1];
+  for (int i = tid; i < nent; i += (int)blockDim.x) s_pose[i] = v.ent_pose[e0 + i];
   const int stages_total = HW / SY_TPX;  // v.wide guarantees HW % 32 == 0
   const int spw = (stages_total + gridDim.y - 1) / gridDim.y;
   const int st_beg = blockIdx.y * spw, st_end = min(stages_total, st_beg + spw);
@@ -1101,12 +1104,12 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
           const int lj = 16 * tb + r;          // B side, always an E row
           if (lj >= R || li > R) continue;
           const double val = -(double)acc[u][q][x];
-          const int gj = 6 * v.ent_pose[e0 + lj / 6] + lj % 6;
+          const int gj = 6 * s_pose[lj / 6] + lj % 6;
           if (li == R) {  // w row: reduced rhs
             atomicAdd(&v.sys[(size_t)v.n * v.ld + gj], val);
             continue;
           }
-          const int gi = 6 * v.ent_pose[e0 + li / 6] + li % 6;
+          const int gi = 6 * s_pose[li / 6] + li % 6;
           if (ta == tb) {  // diagonal tile: both (li,lj) and (lj,li) are computed
             if (gi >= gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
           } else {  // the mirror element is not computed: fold it into the lower triangle
