@@ -126,3 +126,51 @@ def altcorr_forward(fmap1, fmap2, coords, radius, acc_dtype=None, chunked=True):
                         ch = iy + rd * ix
                         corr[:, n, ch] = (corr[:, n, ch] + (s * w_se).astype(st)).astype(st)
     return corr
+
+
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
+    """Gradients of `altcorr_forward` with respect to the two feature maps (fp64), restating the scatter of
+    altcorr_kernel.cu:152-286: for every query and every one of the (2r+2)^2 integer taps the four bilinear
+    weights combine the matching entries of corr_grad into one scalar g (ak:228-246), then
+    fmap1_grad[query] += g * fmap2[tap] and fmap2_grad[tap] += g * fmap1[query] (taps outside fmap2 are skipped).
+    The coordinate gradient of the reference is identically zero (ak:322-355 returns zeros)."""
+    f1 = np.asarray(fmap1, np.float64)
+    f2 = np.asarray(fmap2, np.float64)
+    cg = np.asarray(corr_grad, np.float64)
+    coords = np.asarray(coords, dtype=np.float32)
+    B, H1, W1, C = f1.shape
+    _, H2, W2, _ = f2.shape
+    N = coords.shape[1]
+    r = int(radius)
+    rd = 2 * r + 1
+    g1 = np.zeros_like(f1)
+    g2 = np.zeros_like(f2)
+    bb = np.broadcast_to(np.arange(B)[:, None, None], (B, H1, W1))
+    one = np.float32(1.0)
+    for n in range(N):
+        x2, y2 = coords[:, n, :, :, 0], coords[:, n, :, :, 1]
+        fx, fy = np.floor(x2), np.floor(y2)
+        dx = (x2 - fx).astype(np.float32)
+        dy = (y2 - fy).astype(np.float32)
+        fxi, fyi = fx.astype(np.int64), fy.astype(np.int64)
+        # the four bilinear weights as the forward forms them: fp32 products (ak:119-122)
+        w_nw, w_ne = (dy * dx).astype(np.float64), (dy * (one - dx)).astype(np.float64)
+        w_sw, w_se = ((one - dy) * dx).astype(np.float64), ((one - dy) * (one - dx)).astype(np.float64)
+        for iy in range(rd + 1):
+            for ix in range(rd + 1):
+                h2, w2 = fyi - r + iy, fxi - r + ix
+                inb = (h2 >= 0) & (h2 < H2) & (w2 >= 0) & (w2 < W2)
+                g = np.zeros((B, H1, W1))
+                if iy > 0 and ix > 0:
+                    g += cg[:, n, (iy - 1) + rd * (ix - 1)] * w_nw
+                if iy > 0 and ix < rd:
+                    g += cg[:, n, (iy - 1) + rd * ix] * w_ne
+                if iy < rd and ix > 0:
+                    g += cg[:, n, iy + rd * (ix - 1)] * w_sw
+                if iy < rd and ix < rd:
+                    g += cg[:, n, iy + rd * ix] * w_se
+                g = np.where(inb, g, 0.0)
+                hc, wc = np.clip(h2, 0, H2 - 1), np.clip(w2, 0, W2 - 1)
+                g1 += g[..., None] * f2[bb, hc, wc]
+                np.add.at(g2, (bb, hc, wc), g[..., None] * f1)
+    return g1, g2

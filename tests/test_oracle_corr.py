@@ -92,3 +92,21 @@ def test_corr_golden_vectors(oracle):
     assert np.array_equal(oracle.corr_index_forward(g["volume"].astype(np.float32), g["coords"], 3), g["corr_f32"])
     alt = oracle.altcorr_forward(g["fmap1"], g["fmap2"], g["alt_coords"], 3, acc_dtype=np.float64)
     assert np.abs(alt - g["altcorr"]).max() < 1e-12
+
+
+def test_altcorr_backward_is_the_adjoint_of_the_forward():
+    """altcorr_forward is linear in each feature map, so <corr_grad, F(d1, f2)> = <g1, d1> and
+    <corr_grad, F(f1, d2)> = <g2, d2> for any directions d1, d2 (fp64, includes out-of-range taps)."""
+    from oracle import corr as oc
+    rng = np.random.default_rng(4)
+    B, H, W, C, N, r = 2, 6, 7, 8, 2, 2
+    f1, f2 = rng.normal(size=(B, H, W, C)), rng.normal(size=(B, H, W, C))
+    coords = rng.uniform(-2.5, max(H, W) + 1.5, (B, N, H, W, 2)).astype(np.float32)
+    cg = rng.normal(size=(B, N, (2 * r + 1) ** 2, H, W))
+    g1, g2 = oc.altcorr_backward(f1, f2, coords, cg, r)
+    for _ in range(3):
+        d1, d2 = rng.normal(size=f1.shape), rng.normal(size=f2.shape)
+        a1 = np.sum(cg * oc.altcorr_forward(d1, f2, coords, r, acc_dtype=np.float64, chunked=False))
+        a2 = np.sum(cg * oc.altcorr_forward(f1, d2, coords, r, acc_dtype=np.float64, chunked=False))
+        assert abs(a1 - np.sum(g1 * d1)) < 1e-9 * max(1.0, abs(a1))
+        assert abs(a2 - np.sum(g2 * d2)) < 1e-9 * max(1.0, abs(a2))
