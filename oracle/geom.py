@@ -68,3 +68,42 @@ def motion_features(poses, disps, intrinsics, ii, jj, target):
     coords0 = np.stack([x, y], axis=-1)
     motn = np.concatenate([coords - coords0[None], np.asarray(target, np.float64) - coords], axis=-1)
     return np.clip(motn.transpose(0, 3, 1, 2), -64.0, 64.0), coords, valid
+
+
+def depth_filter(poses, disps, intrinsics, ix, thresh):
+    """counter [num,H,W] of droid_kernels.cu:661-775 (depth_filter_kernel): for each selected frame ix and each of
+    its six temporal neighbours jx = ix-1, ix-2, ix-3, ix+3, ix+4, ix+5 (:695 -- the kernel's own enumeration),
+    every pixel is moved into jx with the relative pose WITHOUT the stereo special case, and the neighbour counts 1
+    when the inverse of its transformed disparity is within `thresh` of the inverse disparity of one of the four
+    pixels around its projection (:763-767; the comparison is carried out in double precision there, `1.0/dj`).
+    Projections whose integer corner is outside [0,W-1) x [0,H-1) do not count (:748)."""
+    poses = np.asarray(poses, np.float64)
+    disps = np.asarray(disps, np.float64)
+    K = np.asarray(intrinsics, np.float64)
+    ix = np.asarray(ix, np.int64)
+    thresh = np.asarray(thresh, np.float64)
+    nbuf, H, W = disps.shape
+    y, x = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    out = np.zeros((len(ix), H, W))
+    for b, i in enumerate(ix):
+        if i < 0 or i >= nbuf:
+            continue
+        for nb in range(6):
+            j = i - nb - 1 if nb < 3 else i + nb
+            if j < 0 or j >= nbuf:
+                continue
+            t, q = _relative(poses, np.array([i]), np.array([j]))   # i != j for the six offsets: no stereo rule
+            X0 = np.stack([(x - K[2]) / K[0], (y - K[3]) / K[1], np.ones((H, W))], axis=-1)
+            X1 = _quat_rot(q[0][None, None, :], X0) + t[0][None, None, :] * disps[i][..., None]
+            uj = K[0] * (X1[..., 0] / X1[..., 2]) + K[2]
+            vj = K[1] * (X1[..., 1] / X1[..., 2]) + K[3]
+            dj = disps[i] / X1[..., 2]
+            u0, v0 = np.floor(uj).astype(np.int64), np.floor(vj).astype(np.int64)
+            ok = (u0 >= 0) & (v0 >= 0) & (u0 < W - 1) & (v0 < H - 1)
+            u0c, v0c = np.clip(u0, 0, W - 2), np.clip(v0, 0, H - 2)
+            hit = np.zeros((H, W), bool)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                for dv, du in ((0, 0), (0, 1), (1, 0), (1, 1)):
+                    hit |= np.abs(1.0 / dj - 1.0 / disps[j][v0c + dv, u0c + du]) < thresh[b]
+            out[b] += (hit & ok)
+    return out

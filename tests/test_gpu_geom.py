@@ -118,3 +118,21 @@ def test_reproject_rejects_cpu_tensors_and_bad_indices(backends, prob):
     ii[0] = 10 ** 6
     c, v = backends.reproject(d["poses"], d["disps"], d["intrinsics"], ii, d["jj"])
     assert float(c[0, 0].abs().max()) == 0.0 and float(v[0, 0].max()) == 0.0   # out-of-range edge: zeros, no fault
+
+
+def test_depth_filter_matches_oracle(backends, prob):
+    """depth_filter counts (droid_kernels.cu:661-775) against the numpy restatement: perturbed poses, frames at
+    both ends of the buffer (missing neighbours), an index outside the buffer.  The reference compares in
+    double precision, the kernel in fp32: pixels whose error sits on the threshold may differ by one count."""
+    torch = _torch()
+    from oracle import geom
+    d = to_dev(prob, torch)
+    nb = prob.disps.shape[0]
+    ix = np.array([0, 2, nb // 2, nb - 1, nb + 3], dtype=np.int64)
+    thresh = np.array([0.05, 0.1, 0.2, 0.02, 0.1], dtype=np.float32)
+    got = backends.depth_filter(d["poses"], d["disps"], d["intrinsics"], torch.from_numpy(ix).cuda(),
+                                torch.from_numpy(thresh).cuda()).cpu().numpy()
+    ref = geom.depth_filter(prob.poses, prob.disps, prob.intrinsics, ix, thresh)
+    assert got.shape == ref.shape and got[-1].max() == 0 and ref[-1].max() == 0
+    assert np.abs(got - ref).max() <= 1.0 and np.mean(got != ref) < 2e-3
+    assert ref[:4].max() >= 3 and (ref[:4] == 0).any()      # the case is not trivial

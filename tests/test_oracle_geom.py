@@ -79,3 +79,18 @@ def test_per_frame_intrinsics_and_motion_feature_layout():
     assert motn.shape == (2, 4, 12, 16) and np.array_equal(c, c2)
     assert motn.max() <= 64.0 and motn.min() >= -64.0
     assert np.allclose(motn[:, 0], np.clip(c[..., 0] - x, -64, 64)) and np.allclose(motn[:, 3], np.clip((target - c)[..., 1], -64, 64))
+
+
+def test_depth_filter_counts_existing_neighbours_of_a_static_scene():
+    """Identity poses, constant disparity: every neighbour that exists agrees, except where the 2x2 corner of the
+    (unchanged) projection leaves the image (last row / column, droid_kernels.cu:748)."""
+    poses = np.zeros((9, 7)); poses[:, 6] = 1.0
+    disps = np.full((9, 10, 12), 0.7)
+    K = np.array([20.0, 20.0, 5.5, 4.5])
+    ix = np.array([0, 4, 8, 12])
+    cnt = geom.depth_filter(poses, disps, K, ix, np.full(4, 0.01))
+    # neighbours ix-1, ix-2, ix-3, ix+3, ix+4, ix+5 inside [0, 9)
+    assert np.all(cnt[0, :-1, :-1] == 3) and np.all(cnt[1, :-1, :-1] == 4) and np.all(cnt[2, :-1, :-1] == 3)
+    assert np.all(cnt[:, -1, :] == 0) and np.all(cnt[:, :, -1] == 0) and np.all(cnt[3] == 0)
+    disps[5] = 1.4          # frame 5 disagrees: 1/0.7 - 1/1.4 = 0.71 > threshold (neighbour ix-3 of frame 8)
+    assert np.all(geom.depth_filter(poses, disps, K, np.array([8]), np.array([0.01]))[0, :-1, :-1] == 2)
