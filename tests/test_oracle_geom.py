@@ -90,7 +90,7 @@ def test_depth_filter_counts_existing_neighbours_of_a_static_scene():
     ix = np.array([0, 4, 8, 12])
     cnt = geom.depth_filter(poses, disps, K, ix, np.full(4, 0.01))
     # neighbours ix-1, ix-2, ix-3, ix+3, ix+4, ix+5 inside [0, 9)
-    assert np.all(cnt[0, :-1, :-1] == 3) and np.all(cnt[1, :-1, :-1] == 4) and np.all(cnt[2, :-1, :-1] == 3)
+    assert np.all(cnt[0, :-1, :-1] == 3) and np.all(cnt[1, :-1, :-1] == 5) and np.all(cnt[2, :-1, :-1] == 3)
     assert np.all(cnt[:, -1, :] == 0) and np.all(cnt[:, :, -1] == 0) and np.all(cnt[3] == 0)
     disps[5] = 1.4          # frame 5 disagrees: 1/0.7 - 1/1.4 = 0.71 > threshold (neighbour ix-3 of frame 8)
     assert np.all(geom.depth_filter(poses, disps, K, np.array([8]), np.array([0.01]))[0, :-1, :-1] == 2)
