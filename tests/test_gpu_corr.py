@@ -99,12 +99,12 @@ def _alt_inputs(B, H, W, lvl, C, seed):
     return f1, f2, coords
 
 
-@pytest.mark.parametrize("lvl,C,N", [(0, 128, 1), (2, 48, 2), (1, 272, 1)])
-def test_altcorr_backward_matches_oracle(backends, oracle, lvl, C, N):
+@pytest.mark.parametrize("lvl,C,N,r", [(0, 128, 1, 3), (2, 48, 2, 3), (1, 272, 1, 3), (0, 40, 1, 3), (1, 64, 1, 4)])
+def test_altcorr_backward_matches_oracle(backends, oracle, lvl, C, N, r):
     """fmap gradients of altcorr (altcorr_kernel.cu:152-286) against the fp64 restatement (itself checked to be
     the adjoint of the forward, tests/test_oracle_corr.py): fp32 atomics, 2e-5 of the gradient scale; the
     coordinate gradient is identically zero like the reference's.  C = 272 takes the path without the register
-    accumulation of the query's own gradient."""
+    accumulation of the query's own gradient, C = 40 a channel count that is not a multiple of 16."""
     torch = _torch()
     from oracle import corr as oc
     f1, f2, coords = _alt_inputs(2, 12, 16, lvl, C, seed=10 + lvl)
@@ -112,13 +112,13 @@ def test_altcorr_backward_matches_oracle(backends, oracle, lvl, C, N):
         coords = np.concatenate([coords, coords + np.float32(0.37)], axis=1)
     coords[0, 0, 0, :3] = [[-9.0, -9.0], [1e4, 3.0], [2.5, -0.5]]   # windows partly or wholly outside fmap2
     rng = np.random.default_rng(5)
-    cg = rng.normal(size=(2, N, 49, 12, 16)).astype(np.float32)
-    r1, r2 = oc.altcorr_backward(f1, f2, coords, cg, 3)
+    cg = rng.normal(size=(2, N, (2 * r + 1) ** 2, 12, 16)).astype(np.float32)
+    r1, r2 = oc.altcorr_backward(f1, f2, coords, cg, r)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    g1, g2, gc = backends.altcorr_backward(t(f1), t(f2), t(coords), t(cg), 3)
+    g1, g2, gc = backends.altcorr_backward(t(f1), t(f2), t(coords), t(cg), r)
     e1 = np.abs(g1.cpu().numpy() - r1).max() / np.abs(r1).max()
     e2 = np.abs(g2.cpu().numpy() - r2).max() / np.abs(r2).max()
-    print(f"altcorr backward lvl{lvl} C={C} N={N}: rel err {e1:.2e} {e2:.2e}")
+    print(f"altcorr backward lvl{lvl} C={C} N={N} r={r}: rel err {e1:.2e} {e2:.2e}")
     assert e1 < 2e-5 and e2 < 2e-5
     assert float(gc.abs().max()) == 0.0
 
