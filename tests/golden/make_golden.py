@@ -52,6 +52,29 @@ def main():
     alt = oracle.altcorr_forward(f1, f2, ac, 3, acc_dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, "corr_golden.npz"), volume=vol, coords=coords, corr_f16=c16,
                         corr_f32=c32, fmap1=f1, fmap2=f2, alt_coords=ac, altcorr=alt)
+    # gradients of the alt-correlation on the same inputs
+    cg = rng.normal(0, 1, alt.shape).astype(np.float32)
+    from oracle import corr as ocorr, geom as ogeom
+    g1, g2 = ocorr.altcorr_backward(f1, f2, ac, cg, 3)
+    np.savez_compressed(os.path.join(HERE, "altcorr_backward_golden.npz"), fmap1=f1, fmap2=f2, coords=ac, corr_grad=cg,
+                        fmap1_grad=g1, fmap2_grad=g2)
+
+    # reprojection + motion features and depth_filter on a small scene (per-frame intrinsics, one stereo edge,
+    # one frame pushed behind the others)
+    p = synth.make_ba_problem(N=6, E=14, H=12, W=16, seed=31)
+    poses = p.poses.copy()
+    poses[4, :3] += np.array([0.0, 0.0, -5.0], np.float32)
+    K = np.stack([p.intrinsics * np.float32(1.0 + 0.02 * f) for f in range(p.disps.shape[0])]).astype(np.float32)
+    ii = np.concatenate([p.ii, [2]]).astype(np.int64)
+    jj = np.concatenate([p.jj, [2]]).astype(np.int64)
+    target = rng.uniform(-10, 40, (len(ii), 12, 16, 2)).astype(np.float32)
+    motn, coords1, valid = ogeom.motion_features(poses, p.disps, K, ii, jj, target)
+    ix = np.array([0, 2, 5], np.int64)
+    th = np.array([0.05, 0.2, 0.1], np.float32)
+    cnt = ogeom.depth_filter(p.poses, p.disps, p.intrinsics, ix, th)
+    np.savez_compressed(os.path.join(HERE, "geom_golden.npz"), poses=poses, disps=p.disps, intrinsics=K, ii=ii, jj=jj,
+                        target=target, motn=motn, coords=coords1, valid=valid, df_poses=p.poses,
+                        df_intrinsics=p.intrinsics, df_ix=ix, df_thresh=th, df_counter=cnt)
     print("wrote", os.listdir(HERE))
 
 

@@ -136,3 +136,22 @@ def test_depth_filter_matches_oracle(backends, prob):
     assert got.shape == ref.shape and got[-1].max() == 0 and ref[-1].max() == 0
     assert np.abs(got - ref).max() <= 1.0 and np.mean(got != ref) < 2e-3
     assert ref[:4].max() >= 3 and (ref[:4] == 0).any()      # the case is not trivial
+
+
+def test_geom_golden_vectors_on_device(backends):
+    """The committed fixtures (tests/golden/geom_golden.npz, altcorr_backward_golden.npz) through the HIP path."""
+    import os
+    torch = _torch()
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "geom_golden.npz"), allow_pickle=False)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    c, v, m = backends.reproject(t(g["poses"]), t(g["disps"]), t(g["intrinsics"]), t(g["ii"]), t(g["jj"]), t(g["target"]))
+    ok = np.abs(g["coords"]).max(axis=-1) < 1e4
+    assert np.abs(c.cpu().numpy()[0] - g["coords"])[ok].max() < 2e-3
+    assert np.mean(v.cpu().numpy()[0] != g["valid"]) < 1e-3 and np.abs(m.cpu().numpy()[0] - g["motn"]).max() < 5e-3
+    cnt = backends.depth_filter(t(g["df_poses"]), t(g["disps"]), t(g["df_intrinsics"]), t(g["df_ix"]), t(g["df_thresh"]))
+    assert np.abs(cnt.cpu().numpy() - g["df_counter"]).max() <= 1.0 and np.mean(cnt.cpu().numpy() != g["df_counter"]) < 5e-3
+    a = np.load(os.path.join(gold, "altcorr_backward_golden.npz"), allow_pickle=False)
+    g1, g2, _ = backends.altcorr_backward(t(a["fmap1"]), t(a["fmap2"]), t(a["coords"]), t(a["corr_grad"]), 3)
+    assert np.abs(g1.cpu().numpy() - a["fmap1_grad"]).max() < 2e-5 * np.abs(a["fmap1_grad"]).max()
+    assert np.abs(g2.cpu().numpy() - a["fmap2_grad"]).max() < 2e-5 * np.abs(a["fmap2_grad"]).max()

@@ -110,3 +110,11 @@ def test_altcorr_backward_is_the_adjoint_of_the_forward():
         a2 = np.sum(cg * oc.altcorr_forward(f1, d2, coords, r, acc_dtype=np.float64, chunked=False))
         assert abs(a1 - np.sum(g1 * d1)) < 1e-9 * max(1.0, abs(a1))
         assert abs(a2 - np.sum(g2 * d2)) < 1e-9 * max(1.0, abs(a2))
+
+
+def test_altcorr_backward_golden_vectors():
+    """Regression pin of the gradient restatement (tests/golden/make_golden.py)."""
+    from oracle import corr as oc
+    g = np.load(os.path.join(GOLD, "altcorr_backward_golden.npz"), allow_pickle=False)
+    g1, g2 = oc.altcorr_backward(g["fmap1"], g["fmap2"], g["coords"], g["corr_grad"], 3)
+    assert np.abs(g1 - g["fmap1_grad"]).max() < 1e-12 and np.abs(g2 - g["fmap2_grad"]).max() < 1e-12

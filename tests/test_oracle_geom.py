@@ -94,3 +94,15 @@ def test_depth_filter_counts_existing_neighbours_of_a_static_scene():
     assert np.all(cnt[:, -1, :] == 0) and np.all(cnt[:, :, -1] == 0) and np.all(cnt[3] == 0)
     disps[5] = 1.4          # frame 5 disagrees: 1/0.7 - 1/1.4 = 0.71 > threshold (neighbour ix-3 of frame 8)
     assert np.all(geom.depth_filter(poses, disps, K, np.array([8]), np.array([0.01]))[0, :-1, :-1] == 2)
+
+
+def test_geom_golden_vectors():
+    """Regression pin: committed outputs of oracle/geom.py (tests/golden/make_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "geom_golden.npz"), allow_pickle=False)
+    motn, coords, valid = geom.motion_features(g["poses"], g["disps"], g["intrinsics"], g["ii"], g["jj"], g["target"])
+    assert np.array_equal(valid, g["valid"])
+    assert np.abs(coords - g["coords"]).max() < 1e-9 * max(1.0, np.abs(g["coords"]).max())
+    assert np.abs(motn - g["motn"]).max() < 1e-9
+    cnt = geom.depth_filter(g["df_poses"], g["disps"], g["df_intrinsics"], g["df_ix"], g["df_thresh"])
+    assert np.array_equal(cnt, g["df_counter"])
