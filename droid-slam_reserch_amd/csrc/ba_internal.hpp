@@ -12,7 +12,7 @@ constexpr int LIN_CP = LIN_THREADS * LIN_PPT;    // pixels per workgroup chunk
 constexpr int CHOL_NB = 64;                      // Cholesky block size
 // row pitch of the augmented system in doubles: 128-byte rows, so 64-column tiles never share a cache line
 __host__ __device__ inline int chol_ld(int n) { return (n + 1 + 15) & ~15; }
-// ints of hand-off flags (done[], dver[], abort) and doubles of factored diagonal tiles for an n x n solve
+// ints of hand-off flags (done[], dver[], abort) of an n x n solve
 __host__ __device__ inline size_t chol_flag_words(int n) { return 2 * ((size_t)(n + 1 + CHOL_NB - 1) / CHOL_NB) + 8; }
 // lower-triangle tiles of the augmented system in column-major order: tile (bi, bj), bi >= bj
 __host__ __device__ inline int chol_tile_index(int nrb, int bi, int bj) { return bj * nrb - bj * (bj - 1) / 2 + (bi - bj); }
@@ -20,9 +20,11 @@ __host__ __device__ inline size_t chol_tiles(int n) {
   const int nb = (n + CHOL_NB - 1) / CHOL_NB, nrb = (n + 1 + CHOL_NB - 1) / CHOL_NB;
   return (size_t)chol_tile_index(nrb, nb, nb);  // = sum_{j<nb} (nrb - j)
 }
-// `ldiag` scratch: [nb] factored diagonal tiles, [nb] tiles M_j, then [chol_tiles] 64x64 slots `lfin` for the final panel tiles as
-// the panel chain hands them over (data-tagged: preset to 0xFF bytes, a strip is there when its bytes are not)
-// then [nb] tiles M_j = L[j+1,j] L_jj^-1 (the back-substitution multiplies by them instead of solving), then lfin
+// `ldiag` scratch of the single-launch factorisation, in 64x64 tiles:
+//   [nb]         factored diagonal tiles L_jj (+ the inverses of their 16x16 diagonal blocks in the upper part),
+//   [nb]         M_j = L[j+1,j] L_jj^-1 (the back-substitution multiplies by them instead of solving),
+//   [chol_tiles] hand-over slots `lfin` of the final panel tiles (data-tagged: preset to 0xFF bytes, a 16-column
+//                strip is there when its bytes are not)
 __host__ __device__ inline size_t chol_mbuf_offset(int n) { return ((size_t)(n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
 __host__ __device__ inline size_t chol_lfin_offset(int n) { return 2 * chol_mbuf_offset(n); }
 __host__ __device__ inline size_t chol_ldiag_doubles(int n) { return chol_lfin_offset(n) + chol_tiles(n) * CHOL_NB * CHOL_NB; }
