@@ -102,13 +102,17 @@ __device__ __forceinline__ int reduce32_index(int lane) {
 // Per-edge metadata of one depth slot, resident in LDS for the lifetime of a workgroup, so that
 // the per-pixel loops never chase seg_edge -> jj -> poses through dependent global loads.
 constexpr int SLOT_MAXE = 128;  // edges per metadata chunk (slots with more are processed in chunks)
-struct SlotMeta {
+// S = double in the linearisation (fp64 reprojection / residual), float in the Schur and back-substitution
+// kernels (Jacobians only).  The relative pose itself is always evaluated in fp64 (se3.hpp: rel_pose_mat).
+template <typename S>
+struct SlotMetaT {
   int e[SLOT_MAXE];     // edge index
   int pj[SLOT_MAXE];    // target pose index jj - t0 (may be outside [0,P))
   int ent[SLOT_MAXE];   // Schur entry index of the edge within the slot, -1 if its target is not in the window
   int flag[SLOT_MAXE];  // 1 = stereo pair (ii == jj)
-  float T[SLOT_MAXE][8];  // relative pose t[3], q[4]
+  S T[SLOT_MAXE][12];   // relative pose: R (row-major 3x3), t
 };
+typedef SlotMetaT<float> SlotMeta;
 
 constexpr int SF_TP = 64;             // pixels per LDS tile; 4 threads per pixel split the edges
 constexpr int SF_RB = 96;             // rows per block (16 entries)
@@ -128,21 +132,22 @@ __device__ __forceinline__ int schur_class(int rows, int nedges, int wide) {
 
 // Loads edges [x0, x0+cnt) of slot m (cnt <= SLOT_MAXE) by the first cnt threads of the workgroup.
 // ent_base = entry index of the first window edge of this chunk.  Ends with a barrier.
-__device__ __forceinline__ void load_slot_meta(SlotMeta& sm, const BaView& v, const float* __restrict__ poses,
+template <typename S>
+__device__ __forceinline__ void load_slot_meta(SlotMetaT<S>& sm, const BaView& v, const float* __restrict__ poses,
                                                const int64_t* __restrict__ jj, int f, int x0, int cnt,
                                                int ent_base) {
   const int t = threadIdx.x;
   if (t < cnt) {
     const int e = v.seg_edge[x0 + t];
     const int jx = (int)jj[e];
-    const Rel T = rel_pose<true>(poses, f, jx);
+    const RelMat<S> T = rel_pose_mat<S, true>(poses, f, jx);
     sm.e[t] = e;
     sm.pj[t] = jx - v.t0;
     sm.flag[t] = (jx == f) ? 1 : 0;
 #pragma unroll
-    for (int n = 0; n < 3; n++) sm.T[t][n] = T.t[n];
+    for (int n = 0; n < 9; n++) sm.T[t][n] = T.R[n];
 #pragma unroll
-    for (int n = 0; n < 4; n++) sm.T[t][3 + n] = T.q[n];
+    for (int n = 0; n < 3; n++) sm.T[t][9 + n] = T.t[n];
   }
   __syncthreads();
   if (t < cnt) {
@@ -151,15 +156,6 @@ __device__ __forceinline__ void load_slot_meta(SlotMeta& sm, const BaView& v, co
     sm.ent[t] = (sm.pj[t] >= 0 && sm.pj[t] < v.P) ? a : -1;
   }
   __syncthreads();
-}
-
-__device__ __forceinline__ Rel meta_rel(const SlotMeta& sm, int x) {
-  Rel T;
-#pragma unroll
-  for (int n = 0; n < 3; n++) T.t[n] = sm.T[x][n];
-#pragma unroll
-  for (int n = 0; n < 4; n++) T.q[n] = sm.T[x][3 + n];
-  return T;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -320,7 +316,7 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
     const float* __restrict__ targets, const float* __restrict__ weights,
     const float* __restrict__ eta, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj) {
   __shared__ float red[2][LIN_THREADS / 64][32];
-  __shared__ SlotMeta sm;
+  __shared__ SlotMetaT<double> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HW = v.HW, W = v.W;
   const int chunk = blockIdx.y;
@@ -398,14 +394,19 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
     const int xl = DEPTH ? (x - xb) % SLOT_MAXE : 0;
     const int e = DEPTH ? sm.e[xl] : x;
     const int ix = DEPTH ? f : (int)ii[e];
-    Rel T;
+    double Rt[12];   // relative pose of the edge: R (row-major), t
     bool stereo;
     if (DEPTH) {
-      T = meta_rel(sm, xl);
+#pragma unroll
+      for (int n = 0; n < 12; n++) Rt[n] = sm.T[xl][n];
       stereo = sm.flag[xl] != 0;
     } else {
       const int jx = (int)jj[e];
-      T = rel_pose<true>(poses, ix, jx);
+      const RelMat<double> T = rel_pose_mat<double, true>(poses, ix, jx);
+#pragma unroll
+      for (int n = 0; n < 9; n++) Rt[n] = T.R[n];
+#pragma unroll
+      for (int n = 0; n < 3; n++) Rt[9 + n] = T.t[n];
       stereo = (ix == jx);
     }
     // software pipeline: the next edge's targets / weights are in flight while this one is reduced
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
         const int k = pix[p];
         const float d = DEPTH ? disp[p] : disps[(size_t)ix * HW + k];
         const float u = (float)(k % W), vv = (float)(k / W);
-        const PixLin L = linearize_pixel(K, T, u, vv, d, in_cur[p][0], in_cur[p][1]);
+        const PixLin L = linearize_pixel_d(K, Rt, Rt + 9, u, vv, d, in_cur[p][0], in_cur[p][1]);
         float wu = L.valid * (0.001f * in_cur[p][2]);        // dk:305-306
         float wv = L.valid * (0.001f * in_cur[p][3]);
         if (DEPTH) {
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
           }
           if (has_self) {
             float eii[6];
-            adj_se3(T.t, T.q, eij, eii);
+            adjT_mat(Rt, Rt + 9, eij, eii);
 #pragma unroll
             for (int n = 0; n < 6; n++) selfacc[p][n] -= eii[n];
           }
@@ -602,11 +603,11 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaView v, const float* 
   }
   if (t >= 32 && t < 38) {  // column k of A: Adj^T applied to the k-th unit vector
     const int k = t - 32;
-    const Rel T = rel_pose<true>(poses, ix, jx);
-    float X[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Y[6];
-    X[k] = 1.f;
-    adj_se3(T.t, T.q, X, Y);
-    for (int r = 0; r < 6; r++) A[r][k] = (double)Y[r];
+    const RelMat<double> T = rel_pose_mat<double, true>(poses, ix, jx);
+    double X[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, Y[6];
+    X[k] = 1.0;
+    adjT_mat(T.R, T.t, X, Y);
+    for (int r = 0; r < 6; r++) A[r][k] = Y[r];
   }
   __syncthreads();
   const int n = v.n, ld = v.ld;
@@ -670,10 +671,10 @@ __device__ unsigned long long g_schur_stamps[8 * 16];
 constexpr int SF_PITCH = SF_TP + 4;   // 16-byte aligned rows, conflict-free 16-byte MFMA operand reads
 constexpr int SF_MAXT = 11;           // max 16x16 output tiles per wave: ceil(7*6/4)
 
-// E row (6 values, already scaled by `scale`) of one (edge, pixel)
-__device__ __forceinline__ void e_row(const Intr& K, const Rel& T, bool stereo, int k, int W, float disp,
+// E row (6 values) of one (edge, pixel); T = the edge's relative pose (R row-major, t)
+__device__ __forceinline__ void e_row(const Intr& K, const float* T, bool stereo, int k, int W, float disp,
                                       float wu_raw, float wv_raw, float* eij) {
-  const PixLin L = linearize_pixel(K, T, (float)(k % W), (float)(k / W), disp, 0.f, 0.f);
+  const PixLin L = jacobians_pixel(K, T, T + 9, (float)(k % W), (float)(k / W), disp);
   float wu = L.valid * (0.001f * wu_raw), wv = L.valid * (0.001f * wv_raw);
   if (stereo) {
     wu = 0.f;
@@ -756,9 +757,14 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
       const int ta_n = (na + 15) / 16, tb_n = (nb + 15) / 16;
       const int ntiles = (ba == bb) ? ta_n * (ta_n + 1) / 2 : ta_n * tb_n;
       constexpr int MAXT = MULTI ? SF_MAXT : 7;  // one block: at most 7*8/2 = 28 tiles over 4 waves
-      f32x4 acc[MAXT];
+      // fp32 MFMA chains are kept to ONE 64-pixel tile (16 k-steps): the tile result is added to an fp64 total.
+      // A chain over the whole pixel range (512 products) leaves 3e-7 of the block in every partial sum, which
+      // the ill-conditioned reduced system (cond 1e6 on the 256-keyframe graph) turns into 3e-5 of pose error.
+      double tot[MAXT][4];
 #pragma unroll
-      for (int t = 0; t < MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < MAXT; t++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) tot[t][x] = 0.0;
 
       prefetch(tile_beg);
       for (int tile = tile_beg; tile < tile_end; tile++) {
@@ -796,7 +802,9 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
                 const int a = sm.ent[x];
                 const bool in_blk = a >= a_beg && a < a_end;
                 if (!(in_blk || self_here)) continue;
-                const Rel T = meta_rel(sm, x);
+                float T[12];
+#pragma unroll
+                for (int n = 0; n < 12; n++) T[n] = sm.T[x][n];
                 float eij[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (pok) {
                   float wu_raw, wv_raw;
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
                 }
                 if (self_here) {
                   float eii[6];
-                  adj_se3(T.t, T.q, eij, eii);
+                  adjT_mat(T, T + 9, eij, eii);
 #pragma unroll
                   for (int n = 0; n < 6; n++) selfacc[n] -= eii[n];
                 }
@@ -880,7 +888,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
             // 16s+4g+e), identical for both operands
             const float* pa = &EA[(16 * ta + r) * SF_PITCH + 4 * g];
             const float* pb = &Bs[(16 * tb + r) * SF_PITCH + 4 * g];
-            f32x4 c = acc[t];
+            f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s4 = 0; s4 < SF_TP; s4 += 16) {
               const f32x4 av = *reinterpret_cast<const f32x4*>(pa + s4);
@@ -888,7 +896,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
 #pragma unroll
               for (int e = 0; e < 4; e++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], c, 0, 0, 0);
             }
-            acc[t] = c;
+#pragma unroll
+            for (int x = 0; x < 4; x++) tot[t][x] += (double)c[x];
           }
         }
       }
@@ -918,7 +927,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
             const int li = ra0 + 16 * ta + 4 * g + x;  // global row index within the slot (A side)
             const int lj = rb0 + 16 * tb + r;          // B side, always an E row
             if (lj >= R || li > R) continue;
-            const double val = -(double)acc[t][x];
+            const double val = -tot[t][x];
             const int gj = 6 * (MULTI ? v.ent_pose[e0 + lj / 6] : s_pose[lj / 6]) + lj % 6;
             if (li == R) {  // w row: reduced rhs
               atomicAdd(&v.sys[(size_t)v.n * v.ld + gj], val);
@@ -1179,11 +1188,11 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
       float c[6];
       for (int n = 0; n < 6; n++) c[n] = (on && !failed) ? (float)xsol[6 * pj + n] : 0.f;
       if (self_on) {
-        const Rel T = meta_rel(sm, threadIdx.x);
+        const float* T = sm.T[threadIdx.x];
         for (int k = 0; k < 6; k++) {  // (Adj d)_k = (Adj^T e_k) . d
           float ek[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, col[6];
           ek[k] = 1.f;
-          adj_se3(T.t, T.q, ek, col);
+          adjT_mat(T, T + 9, ek, col);
           float z = 0.f;
           for (int n = 0; n < 6; n++) z += col[n] * dxi[n];
           c[k] -= z;
@@ -1196,7 +1205,9 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
     for (int x = 0; x < cnt; x++) {
       const bool edge_on = sm.ent[x] != 0;
       if (!(edge_on || self_on)) continue;
-      const Rel T = meta_rel(sm, x);
+      float T[12];
+#pragma unroll
+      for (int n = 0; n < 12; n++) T[n] = sm.T[x][n];
       const float* wg = weights + (size_t)sm.e[x] * 2 * HW;
       float wraw[BSUB_PPT][2];
 #pragma unroll

@@ -41,7 +41,12 @@ __device__ __forceinline__ void adj_se3(const float* t, const float* q, const fl
   Y[5] += v[2];
 }
 
-// Tij = Tj * Ti^-1, dk:96-107; stereo pair (ix == jx): fixed baseline, dk:219-229
+// Tij = Tj * Ti^-1, dk:96-107; stereo pair (ix == jx): fixed baseline, dk:219-229.
+// Evaluated in fp64 and rounded once: t = tj - R ti is a difference of two vectors of the size of the
+// trajectory (12 m at 256 keyframes against a baseline of 0.1 m), which in fp32 costs two digits of the
+// relative translation -- an error shared by ALL pixels of the edge, so it does not average out in the
+// normal equations (measured: reduced rhs 4e-6 -> see DESIGN.md section 5).  One evaluation per edge and
+// workgroup; the per-pixel arithmetic stays fp32 like the reference's.
 template <bool STEREO = true>
 __device__ __forceinline__ Rel rel_pose(const float* __restrict__ poses, int ix, int jx) {
   Rel r;
@@ -52,20 +57,82 @@ __device__ __forceinline__ Rel rel_pose(const float* __restrict__ poses, int ix,
   }
   const float* pi = poses + 7 * (size_t)ix;
   const float* pj = poses + 7 * (size_t)jx;
-  const float ti[3] = {pi[0], pi[1], pi[2]};
-  const float qi[4] = {pi[3], pi[4], pi[5], pi[6]};
-  const float tj[3] = {pj[0], pj[1], pj[2]};
-  const float qj[4] = {pj[3], pj[4], pj[5], pj[6]};
-  r.q[0] = -qj[3] * qi[0] + qj[0] * qi[3] - qj[1] * qi[2] + qj[2] * qi[1];
-  r.q[1] = -qj[3] * qi[1] + qj[1] * qi[3] - qj[2] * qi[0] + qj[0] * qi[2];
-  r.q[2] = -qj[3] * qi[2] + qj[2] * qi[3] - qj[0] * qi[1] + qj[1] * qi[0];
-  r.q[3] = qj[3] * qi[3] + qj[0] * qi[0] + qj[1] * qi[1] + qj[2] * qi[2];
-  float rt[3];
-  act_so3(r.q, ti, rt);
-  r.t[0] = tj[0] - rt[0];
-  r.t[1] = tj[1] - rt[1];
-  r.t[2] = tj[2] - rt[2];
+  const double ti[3] = {pi[0], pi[1], pi[2]};
+  const double qi[4] = {pi[3], pi[4], pi[5], pi[6]};
+  const double tj[3] = {pj[0], pj[1], pj[2]};
+  const double qj[4] = {pj[3], pj[4], pj[5], pj[6]};
+  double q[4];
+  q[0] = -qj[3] * qi[0] + qj[0] * qi[3] - qj[1] * qi[2] + qj[2] * qi[1];
+  q[1] = -qj[3] * qi[1] + qj[1] * qi[3] - qj[2] * qi[0] + qj[0] * qi[2];
+  q[2] = -qj[3] * qi[2] + qj[2] * qi[3] - qj[0] * qi[1] + qj[1] * qi[0];
+  q[3] = qj[3] * qi[3] + qj[0] * qi[0] + qj[1] * qi[1] + qj[2] * qi[2];
+  // rt = q * ti (dk:58-68 in double)
+  const double uv0 = 2.0 * (q[1] * ti[2] - q[2] * ti[1]);
+  const double uv1 = 2.0 * (q[2] * ti[0] - q[0] * ti[2]);
+  const double uv2 = 2.0 * (q[0] * ti[1] - q[1] * ti[0]);
+  const double rt0 = ti[0] + q[3] * uv0 + (q[1] * uv2 - q[2] * uv1);
+  const double rt1 = ti[1] + q[3] * uv1 + (q[2] * uv0 - q[0] * uv2);
+  const double rt2 = ti[2] + q[3] * uv2 + (q[0] * uv1 - q[1] * uv0);
+  r.t[0] = (float)(tj[0] - rt0);
+  r.t[1] = (float)(tj[1] - rt1);
+  r.t[2] = (float)(tj[2] - rt2);
+#pragma unroll
+  for (int n = 0; n < 4; n++) r.q[n] = (float)q[n];
   return r;
+}
+
+// The same relative transform as a rotation MATRIX + translation: x' = R x + d t costs 12 FMAs per pixel
+// against ~30 operations of the quaternion sandwich (act_so3), and Adj^T needs only R^T and t.
+// R = I + 2 w [v]x + 2 [v]x^2 is act_so3's own expression (dk:58-68) collected per matrix entry, so it
+// agrees with it for the not-renormalised quaternions of the reference too.  S = double: per-edge values for
+// the residual evaluation of the linearisation; S = float: per-pixel Jacobian arithmetic.
+template <typename S>
+struct RelMat {
+  S R[9];  // row-major
+  S t[3];
+};
+
+template <typename S, bool STEREO = true>
+__device__ __forceinline__ RelMat<S> rel_pose_mat(const float* __restrict__ poses, int ix, int jx) {
+  RelMat<S> r;
+  if (STEREO && ix == jx) {
+#pragma unroll
+    for (int n = 0; n < 9; n++) r.R[n] = (S)((n % 4) == 0 ? 1.0 : 0.0);
+    r.t[0] = (S)(-0.1f); r.t[1] = (S)0.0; r.t[2] = (S)0.0;   // the reference's fp32 literal (dk:221)
+    return r;
+  }
+  const float* pi = poses + 7 * (size_t)ix;
+  const float* pj = poses + 7 * (size_t)jx;
+  const double ti[3] = {pi[0], pi[1], pi[2]};
+  const double qi[4] = {pi[3], pi[4], pi[5], pi[6]};
+  const double tj[3] = {pj[0], pj[1], pj[2]};
+  const double qj[4] = {pj[3], pj[4], pj[5], pj[6]};
+  const double x = -qj[3] * qi[0] + qj[0] * qi[3] - qj[1] * qi[2] + qj[2] * qi[1];
+  const double y = -qj[3] * qi[1] + qj[1] * qi[3] - qj[2] * qi[0] + qj[0] * qi[2];
+  const double z = -qj[3] * qi[2] + qj[2] * qi[3] - qj[0] * qi[1] + qj[1] * qi[0];
+  const double w = qj[3] * qi[3] + qj[0] * qi[0] + qj[1] * qi[1] + qj[2] * qi[2];
+  double R[9];
+  R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - z * w);       R[2] = 2.0 * (x * z + y * w);
+  R[3] = 2.0 * (x * y + z * w);       R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - x * w);
+  R[6] = 2.0 * (x * z - y * w);       R[7] = 2.0 * (y * z + x * w);       R[8] = 1.0 - 2.0 * (x * x + y * y);
+#pragma unroll
+  for (int n = 0; n < 9; n++) r.R[n] = (S)R[n];
+#pragma unroll
+  for (int n = 0; n < 3; n++) r.t[n] = (S)(tj[n] - (R[3 * n] * ti[0] + R[3 * n + 1] * ti[1] + R[3 * n + 2] * ti[2]));
+  return r;
+}
+
+// Y = Adj(T)^T X (dk:79-94) from the matrix form: Y[0:3] = R^T X[0:3], Y[3:6] = R^T (X[3:6] + X[0:3] x t)
+template <typename S, typename V>
+__device__ __forceinline__ void adjT_mat(const S* R, const S* t, const V* X, V* Y) {
+  const V u0 = X[3] + (X[1] * (V)t[2] - X[2] * (V)t[1]);
+  const V u1 = X[4] + (X[2] * (V)t[0] - X[0] * (V)t[2]);
+  const V u2 = X[5] + (X[0] * (V)t[1] - X[1] * (V)t[0]);
+#pragma unroll
+  for (int n = 0; n < 3; n++) {
+    Y[n] = (V)R[n] * X[0] + (V)R[3 + n] * X[1] + (V)R[6 + n] * X[2];
+    Y[3 + n] = (V)R[n] * u0 + (V)R[3 + n] * u1 + (V)R[6 + n] * u2;
+  }
 }
 
 // relSE3 without the stereo special case (projmap / frame_distance / depth_filter, dk:480, :582)
@@ -96,6 +163,26 @@ struct PixLin {
   float valid;         // 0 when Z < MIN_DEPTH (weights are zeroed)     dk:302-306
 };
 
+// Jacobian rows from the transformed point (x, y, 1/Z = d, disparity h) and the edge's translation
+__device__ __forceinline__ void pix_jacobians(const Intr& K, float x, float y, float d, float h, float t0,
+                                              float t1, float t2, PixLin& L) {
+  const float d2 = d * d;
+  L.Ju[0] = K.fx * (h * d);
+  L.Ju[1] = 0.f;
+  L.Ju[2] = K.fx * (-x * h * d2);
+  L.Ju[3] = K.fx * (-x * y * d2);
+  L.Ju[4] = K.fx * (1.f + x * x * d2);
+  L.Ju[5] = K.fx * (-y * d);
+  L.Jzu = K.fx * (t0 * d - t2 * (x * d2));
+  L.Jv[0] = 0.f;
+  L.Jv[1] = K.fy * (h * d);
+  L.Jv[2] = K.fy * (-y * h * d2);
+  L.Jv[3] = K.fy * (-1.f - y * y * d2);
+  L.Jv[4] = K.fy * (x * y * d2);
+  L.Jv[5] = K.fy * (x * d);
+  L.Jzv = K.fy * (t1 * d - t2 * (y * d2));
+}
+
 __device__ __forceinline__ PixLin linearize_pixel(const Intr& K, const Rel& T, float u, float v,
                                                   float disp, float tu, float tv) {
   float Xj[4];
@@ -103,25 +190,55 @@ __device__ __forceinline__ PixLin linearize_pixel(const Intr& K, const Rel& T, f
   const float x = Xj[0], y = Xj[1], h = Xj[3];
   const bool bad = Xj[2] < DROID_MIN_DEPTH;
   const float d = bad ? 0.f : 1.0f / Xj[2];
-  const float d2 = d * d;
   PixLin L;
   L.valid = bad ? 0.f : 1.f;
   L.ru = tu - (K.fx * d * x + K.cx);
   L.rv = tv - (K.fy * d * y + K.cy);
-  L.Ju[0] = K.fx * (h * d);
-  L.Ju[1] = 0.f;
-  L.Ju[2] = K.fx * (-x * h * d2);
-  L.Ju[3] = K.fx * (-x * y * d2);
-  L.Ju[4] = K.fx * (1.f + x * x * d2);
-  L.Ju[5] = K.fx * (-y * d);
-  L.Jzu = K.fx * (T.t[0] * d - T.t[2] * (x * d2));
-  L.Jv[0] = 0.f;
-  L.Jv[1] = K.fy * (h * d);
-  L.Jv[2] = K.fy * (-y * h * d2);
-  L.Jv[3] = K.fy * (-1.f - y * y * d2);
-  L.Jv[4] = K.fy * (x * y * d2);
-  L.Jv[5] = K.fy * (x * d);
-  L.Jzv = K.fy * (T.t[1] * d - T.t[2] * (y * d2));
+  pix_jacobians(K, x, y, d, h, T.t[0], T.t[1], T.t[2], L);
+  return L;
+}
+
+// Jacobians only (E rows of the Schur complement and of the back-substitution), fp32 matrix form:
+// 12 FMAs for the transform.  ru / rv are not set.
+__device__ __forceinline__ PixLin jacobians_pixel(const Intr& K, const float* R, const float* t, float u, float v,
+                                                  float disp) {
+  const float X0 = (u - K.cx) / K.fx, X1 = (v - K.cy) / K.fy;
+  const float x = R[0] * X0 + R[1] * X1 + R[2] + disp * t[0];
+  const float y = R[3] * X0 + R[4] * X1 + R[5] + disp * t[1];
+  const float z = R[6] * X0 + R[7] * X1 + R[8] + disp * t[2];
+  const bool bad = z < DROID_MIN_DEPTH;
+  const float d = bad ? 0.f : 1.0f / z;
+  PixLin L;
+  L.valid = bad ? 0.f : 1.f;
+  L.ru = 0.f;
+  L.rv = 0.f;
+  pix_jacobians(K, x, y, d, disp, t[0], t[1], t[2], L);
+  return L;
+}
+
+// Linearisation with the reprojection and the residual evaluated in fp64 (fp64 FMAs issue at the fp32
+// rate on gfx950): in fp32 the projected coordinate (up to 64..128 px) carries 1e-5 px of rounding, i.e.
+// 3e-5 of a typical 0.3 px residual, which the depth back-substitution dz = Q (w - E^T dx) hands through
+// to weakly observed pixels (measured: 1e-4 of a disparity that moves by 1.4 in two iterations).  The
+// Jacobians are formed in fp32 from the rounded point, like the reference's.
+__device__ __forceinline__ PixLin linearize_pixel_d(const Intr& K, const double* R, const double* t, float u, float v,
+                                                    float disp, float tu, float tv) {
+  const double X0 = ((double)u - (double)K.cx) / (double)K.fx, X1 = ((double)v - (double)K.cy) / (double)K.fy;
+  const double dd = (double)disp;
+  const double x = R[0] * X0 + R[1] * X1 + R[2] + dd * t[0];
+  const double y = R[3] * X0 + R[4] * X1 + R[5] + dd * t[1];
+  const double z = R[6] * X0 + R[7] * X1 + R[8] + dd * t[2];
+  const bool bad = z < (double)DROID_MIN_DEPTH;
+  // 1/z: fp32 reciprocal refined by two Newton steps in fp64 (relative error 1e-7 -> 1e-14 -> 1e-28)
+  double d = (double)(1.0f / (float)z);
+  d = d * (2.0 - z * d);
+  d = d * (2.0 - z * d);
+  if (bad) d = 0.0;
+  PixLin L;
+  L.valid = bad ? 0.f : 1.f;
+  L.ru = (float)((double)tu - ((double)K.fx * d * x + (double)K.cx));
+  L.rv = (float)((double)tv - ((double)K.fy * d * y + (double)K.cy));
+  pix_jacobians(K, (float)x, (float)y, (float)d, disp, (float)t[0], (float)t[1], (float)t[2], L);
   return L;
 }
 

@@ -12,6 +12,11 @@
 
 #define MIN_DEPTH 0.25 /* /root/reference/src/droid_kernels.cu:26 */
 
+/* 1: droid_oracle_ba_* rounds dx, dz, poses and disps to float32 after every iteration (the reference's
+ * tensor dtypes; see the comment in droid_oracle_ba).  Arithmetic stays in REAL. */
+static int g_storage_f32 = 0;
+void droid_oracle_set_storage_f32(int on) { g_storage_f32 = on; }
+
 #define REAL double
 #define SUFFIX _f64
 #define SIN sin

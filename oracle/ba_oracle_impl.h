@@ -620,17 +620,32 @@ int FN(droid_oracle_ba)(real *poses, real *disps, const real *intr, const real *
     if (itr == 0 && dbg_H) memcpy(dbg_H, Hd, sizeof(double) * (size_t)n * n);
     if (itr == 0 && dbg_b) memcpy(dbg_b, bd, sizeof(double) * n);
     FN(solve_system)(Hd, bd, P, lm, ep, dx);
+    /* storage formats of the reference: dx, dz, poses and disps are float32 tensors (dk:1202-1212 `dx` is
+     * converted to kFloat32, dk:1417 dz = Q * (w - ...) on float tensors, dk:898-946 the retraction kernels
+     * write float).  With g_storage_f32 the fp64 restatement rounds exactly these four to float, so that a
+     * multi-iteration call sees the state the reference's next iteration would see. */
+    if (g_storage_f32)
+      for (int k = 0; k < n; k++) dx[k] = (real)(float)dx[k];
     if (!motion_only) {
       real *dz = (real *)malloc(sizeof(real) * ((size_t)st.M * HW + 1));
       FN(back_substitute)(&st, dx, dz);
+      if (g_storage_f32)
+        for (size_t k = 0; k < (size_t)st.M * HW; k++) dz[k] = (real)(float)dz[k];
       FN(retract_poses)(poses, dx, t0, t1);
       FN(retract_disps)(disps, dz, st.kx, st.M, HW);
+      if (g_storage_f32) {
+        for (int k = 7 * t0; k < 7 * t1; k++) poses[k] = (real)(float)poses[k];
+        for (int q = 0; q < st.M; q++)
+          for (int k = 0; k < HW; k++) disps[(size_t)st.kx[q] * HW + k] = (real)(float)disps[(size_t)st.kx[q] * HW + k];
+      }
       if (dz_out) memcpy(dz_out, dz, sizeof(real) * (size_t)st.M * HW);
       if (kx_out) memcpy(kx_out, st.kx, sizeof(int64_t) * st.M);
       if (M_out) *M_out = st.M;
       free(dz);
     } else {
       FN(retract_poses)(poses, dx, t0, t1);
+      if (g_storage_f32)
+        for (int k = 7 * t0; k < 7 * t1; k++) poses[k] = (real)(float)poses[k];
       if (M_out) *M_out = 0;
     }
     FN(free_depth_state)(&st);

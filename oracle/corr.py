@@ -62,6 +62,51 @@ def corr_index_forward(volume, coords, radius):
     return corr
 
 
+def corr_index_backward(volume_shape, coords, corr_grad, radius):
+    """Gradient of `corr_index_forward` with respect to the volume, restating the scatter of
+    /root/reference/src/correlation_kernels.cu:73-124 (wrapper :157-185: zero-initialised, dtype of the
+    volume): for every query and each of the (2r+2)^2 integer taps inside the plane, g accumulates up to
+    four products corr_grad * scalar_t(weight) in scalar_t, in the order (i-1,j-1)*dx*dy, (i-1,j)*dx*(1-dy),
+    (i,j-1)*(1-dx)*dy, (i,j)*(1-dx)*(1-dy) (ck:106-117), and is added to volume_grad[n][y][x][y1][x1]
+    (each query owns its plane: one add per element onto zero)."""
+    cg = np.asarray(corr_grad)
+    st = cg.dtype
+    coords = np.asarray(coords, dtype=np.float32)
+    B, H1, W1, H2, W2 = volume_shape
+    r = int(radius)
+    rd = 2 * r + 1
+    x0, y0 = coords[:, 0], coords[:, 1]
+    fx, fy = np.floor(x0), np.floor(y0)
+    dx = (x0 - fx).astype(np.float32)
+    dy = (y0 - fy).astype(np.float32)
+    one = np.float32(1.0)
+    w11 = (dx * dy).astype(st)
+    w10 = (dx * (one - dy)).astype(st)
+    w01 = ((one - dx) * dy).astype(st)
+    w00 = ((one - dx) * (one - dy)).astype(st)
+    with np.errstate(invalid="ignore"):
+        fxi = np.where(np.isfinite(fx), fx, -1e6).astype(np.int64)
+        fyi = np.where(np.isfinite(fy), fy, -1e6).astype(np.int64)
+    grad = np.zeros((B, H1, W1, H2, W2), dtype=st)
+    bb, yy, xx = np.meshgrid(np.arange(B), np.arange(H1), np.arange(W1), indexing="ij")
+    for i in range(rd + 1):
+        for j in range(rd + 1):
+            x1 = fxi - r + i
+            y1 = fyi - r + j
+            inb = (x1 >= 0) & (x1 < W2) & (y1 >= 0) & (y1 < H2)
+            g = np.zeros((B, H1, W1), dtype=st)
+            if i > 0 and j > 0:
+                g = (g + (cg[:, i - 1, j - 1] * w11).astype(st)).astype(st)
+            if i > 0 and j < rd:
+                g = (g + (cg[:, i - 1, j] * w10).astype(st)).astype(st)
+            if i < rd and j > 0:
+                g = (g + (cg[:, i, j - 1] * w01).astype(st)).astype(st)
+            if i < rd and j < rd:
+                g = (g + (cg[:, i, j] * w00).astype(st)).astype(st)
+            grad[bb[inb], yy[inb], xx[inb], y1[inb], x1[inb]] = g[inb]
+    return grad
+
+
 def altcorr_forward(fmap1, fmap2, coords, radius, acc_dtype=None, chunked=True):
     """fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C], coords [B,N,H1,W1,2] f32 -> corr [B,N,(2r+1)^2,H1,W1].
 

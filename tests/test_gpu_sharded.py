@@ -21,7 +21,18 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _problem(kind):
+    from droid_backends import synth
+    if kind == "cfg1":
+        return synth.make_config("cfg1")
+    if kind == "dense36":     # > 30 edges per source frame at 16x32: E-row cache + SYRK-only Schur kernel, zsplit
+        return synth.make_ba_problem(N=36, E=1200, H=16, W=32, seed=77, lm=1e-4, ep=0.1)
+    if kind == "cfg4like":    # BASELINE configs[3] density (31 edges / frame) at 48x64 on a quarter of the frames
+        return synth.make_ba_problem(N=64, E=2000, H=48, W=64, seed=3, lm=1e-5, ep=1e-2)
+    raise KeyError(kind)
+
+
+def _worker(rank, world, port, out_dir, kind):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -29,8 +40,8 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from droid_backends import ba_driver, synth
-    prob = synth.make_config("cfg1")
+    from droid_backends import ba_driver
+    prob = _problem(kind)
     ranges = ba_driver.partition_frames(prob.ii, prob.t1, world)
     sh = ba_driver.shard_problem(prob, ranges, rank)
     dev = torch.device("cuda", 0)
@@ -49,21 +60,28 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_hip_ba_matches_single_and_oracle(tmp_path, backends, oracle):
+@pytest.mark.parametrize("kind", ["cfg1", "dense36", "cfg4like"])
+def test_two_rank_hip_ba_matches_single_and_oracle(tmp_path, backends, oracle, kind):
+    """cfg1: plumbing; dense36 / cfg4like: every rank holds few, dense depth slots (>= 30 edges per source
+    frame), so the sharded linearisation runs with `zsplit` and the dense-slot SYRK Schur path."""
     import torch
     import torch.multiprocessing as mp
-    from droid_backends import synth
     from util import ba_args, run_hip_ba
     assert torch.cuda.is_available()
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    prob = synth.make_config("cfg1")
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), kind), nprocs=2, join=True)
+    prob = _problem(kind)
+    if kind != "cfg1":
+        assert np.bincount(prob.ii, minlength=prob.t1).mean() >= 30
     single = run_hip_ba(backends, prob, torch, 2)
-    ref = oracle.ba(*ba_args(prob), 2, prob.lm, prob.ep, False)
+    ref = oracle.ba(*ba_args(prob), 2, prob.lm, prob.ep, False, storage_f32=True)
     outs = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(2)]
     for o in outs:
         assert int(o["status"]) & 3 == 0 and int(o["M"]) == int(o["M_expected"])
         assert np.abs(o["poses"] - outs[0]["poses"]).max() == 0.0  # replicated solve is bit-identical
-        assert np.abs(o["poses"] - single["poses"]).max() < 1e-5
+        # sharded vs single GPU: the partial systems are summed in a different order (float32 linearisation
+        # partials are identical, the fp64 reduction is not): float32 resolution of the state times the graph's
+        # conditioning -- 1.5e-5 measured on the dense 64-keyframe graph before the fp64 tile totals
+        assert np.abs(o["poses"] - single["poses"]).max() < 5e-5
         assert np.abs(o["disps"] - single["disps"]).max() < 1e-4
         assert np.abs(o["poses"] - ref["poses"]).max() < 1e-4
         assert np.abs(o["disps"] - ref["disps"]).max() < 1e-4

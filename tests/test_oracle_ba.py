@@ -329,3 +329,20 @@ def test_golden_vectors(oracle, synth):
         assert np.abs(o["poses"] - g[f"{name}_poses"]).max() < 1e-12
         assert np.abs(o["disps"] - g[f"{name}_disps"]).max() < 1e-11
         assert np.abs(o["dx"] - g[f"{name}_dx"]).max() < 1e-12
+
+
+def test_storage_f32_equals_chained_single_iterations(oracle, synth):
+    """oracle.ba(storage_f32=True): dx, dz, poses and disps are rounded to float32 after every iteration (the
+    dtypes of the reference's tensors, dk:1202-1212, :1417, :898-946), arithmetic stays fp64.  Two iterations in
+    that mode must equal two one-iteration calls with the state cast to float32 in between, and the rounding
+    must not move a single-iteration result by more than float32 resolution."""
+    p = synth.make_config("cfg1")
+    two = oracle.ba(*ba_args(p), 2, p.lm, p.ep, False, storage_f32=True)
+    one = oracle.ba(*ba_args(p), 1, p.lm, p.ep, False, storage_f32=True)
+    assert np.array_equal(one["poses"], one["poses"].astype(np.float32).astype(np.float64))
+    again = oracle.ba(one["poses"], one["disps"], p.intrinsics, p.disps_sens, p.targets, p.weights, p.eta, p.ii, p.jj,
+                      p.t0, p.t1, 1, p.lm, p.ep, False, storage_f32=True)
+    assert np.array_equal(again["poses"], two["poses"]) and np.array_equal(again["disps"], two["disps"])
+    plain = oracle.ba(*ba_args(p), 1, p.lm, p.ep, False)
+    assert np.abs(plain["disps"] - one["disps"]).max() < 4e-7 * max(1.0, np.abs(plain["disps"]).max())
+    assert np.abs(plain["poses"] - one["poses"]).max() < 2e-7

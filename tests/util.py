@@ -38,3 +38,41 @@ def compare_state(hip, ref, tag=""):
     edx = np.abs(hip["dx"] - ref["dx"]).max() if hip["dx"].size else 0.0
     print(f"[{tag}] max|dt|={et:.3e} max angle={er:.3e} max|ddisp|={ed:.3e} max|ddx|={edx:.3e}")
     return et, er, ed
+
+
+def stepwise_parity(backends, oracle, p, torch, iterations, tol, tag=""):
+    """PER-ITERATION parity from identical inputs, strict max-norm: iteration k of the device starts from the
+    device's own float32 state after k-1 iterations, and the oracle evaluates that same iteration from the same
+    state.  This is the north star's "match on identical inputs" applied to the map one Gauss-Newton iteration
+    computes; a multi-iteration composite additionally carries the PROBLEM's own sensitivity (see
+    `assert_composite_parity`).  Returns the device state after `iterations` iterations."""
+    import copy
+    q = copy.deepcopy(p)
+    worst = [0.0, 0.0, 0.0]
+    for k in range(iterations):
+        hip = run_hip_ba(backends, q, torch, 1)
+        ref = oracle.ba(*ba_args(q), 1, q.lm, q.ep, False, storage_f32=True)
+        assert hip["status"] & 3 == 0 and hip["M"] == ref["M"]
+        et, er, ed = compare_state(hip, ref, f"{tag} iteration {k + 1} from the device state")
+        assert et < tol and er < tol and ed < tol, (tag, k, et, er, ed)
+        worst = [max(a, b) for a, b in zip(worst, (et, er, ed))]
+        q.poses, q.disps = hip["poses"], hip["disps"]
+    return q, worst
+
+
+def assert_composite_parity(hip, ref, tol, tag="", per_million=8, hard=2e-3):
+    """Composite (multi-iteration) parity: poses strictly within tol; disparities within tol except for at most
+    `per_million` pixels per million, none beyond `hard`.  Why an allowance: a weakly observed depth (C ~ eta,
+    update of 100 % of its value) amplifies a 1-ulp float32 change of the state after iteration 1 by up to ~1e3 in
+    iteration 2 -- measured with the oracle ALONE: rounding its intermediate state to float32, which the
+    reference's float tensors do, moves such a pixel by 5.4e-5 (cfg3 seed 12, pixel (238,1,27)).  Any two float32
+    evaluations (device vs oracle, two edge orders, the reference itself) differ there by ~1e-4; every other pixel
+    and every pose is held to tol."""
+    et, er, ed = compare_state(hip, ref, tag)
+    d = np.abs(hip["disps"] - ref["disps"])
+    n_out = int((d > tol).sum())
+    allow = max(2, int(per_million * 1e-6 * d.size))
+    print(f"[{tag}] disparities beyond {tol:g}: {n_out} of {d.size} (allowed {allow}), max {d.max():.3e}")
+    assert et < tol and er < tol, (tag, et, er)
+    assert n_out <= allow and d.max() < hard, (tag, n_out, allow, float(d.max()))
+    return et, er, ed, n_out
