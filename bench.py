@@ -10,12 +10,15 @@ the clock starts.  K steps are timed as ONE ba call with iterations=K (what
 BASELINE.md section 3 defines: iters/s = K / wall(ba(iterations=K))).
 
 N = 1 : BASELINE.json configs[2], the graph the metric is quoted on (256 keyframes / 2000 edges,
-        48x64, lm=1e-5, ep=1e-2).
-N > 1 : weak scaling of the same graph family: 256 keyframes, 2000*N edges, sharded by source
-        frame (droid_backends/ba_driver.py), one all-reduce (RCCL) of the dense (6P+1)^2 fp64
-        reduced camera system per iteration.  `value` is the whole-job rate in 2000-edge
-        equivalents: iterations/s x (total edges / 2000); the raw iterations/s of the big graph
-        is reported next to it as config.raw_iters_per_sec.
+        48x64, lm=1e-5, ep=1e-2).  `extra.configs_1gpu` adds configs[1] (64 kf / 512 e), configs[3]
+        unsharded (256 kf / 8000 e) and configs[4] (stereo 96x128, 128 kf / 1024 e) on the same GPU.
+N > 1 : BASELINE.json configs[3]: 256 keyframes / 8000 edges IN TOTAL (--edges-total), sharded by source
+        frame over the N ranks (droid_backends/ba_driver.py), one all-reduce (RCCL) of the packed lower
+        triangle of the (6P+1)^2 fp64 reduced camera system per iteration, replicated solve.  Total work is
+        fixed as N grows ("scaling": "strong").  `value` is the whole-job rate in 2000-edge equivalents:
+        iterations/s x (total edges / 2000), so that it is commensurable with the N = 1 line; the raw
+        iterations/s of the 8000-edge graph is config.raw_iters_per_sec.  `extra.weak_scaling` is the second
+        figure: 2000 edges PER GPU (2000*N in total) on the same 256 keyframes.
 
 Rank 0 prints ONE JSON line (see the keys below); everything else goes to stderr.
 """
@@ -47,8 +50,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--edges-per-gpu", type=int, default=2000)
+    ap.add_argument("--edges-total", type=int, default=0, help="0 = 2000 for one GPU, 8000 (BASELINE configs[3]) otherwise")
+    ap.add_argument("--edges-per-gpu", type=int, default=2000, help="weak-scaling second figure (N > 1)")
     ap.add_argument("--keyframes", type=int, default=256)
+    ap.add_argument("--no-extra", action="store_true", help="skip the other configs / the weak-scaling figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-corr", action="store_true")
     ap.add_argument("--corr-edges", type=int, default=256, help="edges per corr-lookup batch")
@@ -59,15 +64,16 @@ def to_dev(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-def bench_ba(args, rank, world, dev):
+def bench_ba(args, rank, world, dev, N, E, H=48, W=64, stereo=False, lm=1e-5, ep=1e-2, seed=2, steps=None,
+             profile=True):
+    """`steps` Gauss-Newton iterations of one `ba` call on an N-keyframe / E-edge graph (E = total over ranks)."""
     import torch.distributed as dist
     from droid_backends import ba_driver, synth
 
-    N, E = args.keyframes, args.edges_per_gpu * world
-    H, W = 48, 64
+    steps = args.steps if steps is None else steps
     t_gen = time.time()
-    prob = synth.make_ba_problem(N=N, E=E, H=H, W=W, lm=1e-5, ep=1e-2, seed=synth.CONFIG_SEEDS["cfg3"])
-    log(f"[rank {rank}] generated {N} kf / {E} edges in {time.time() - t_gen:.1f}s")
+    prob = synth.make_ba_problem(N=N, E=E, H=H, W=W, stereo=stereo, lm=lm, ep=ep, seed=seed)
+    log(f"[rank {rank}] generated {N} kf / {E} edges {H}x{W} in {time.time() - t_gen:.1f}s")
     ranges = ba_driver.partition_frames(prob.ii, N, world)
     sh = ba_driver.shard_problem(prob, ranges, rank)
     p = ba_driver.BAProblemDev(
@@ -93,17 +99,21 @@ def bench_ba(args, rank, world, dev):
     reset()
     barrier()
     t0 = time.perf_counter()
-    solver.run(p, prob.t0, prob.t1, args.steps, prob.lm, prob.ep, own=sh["own"])
+    solver.run(p, prob.t0, prob.t1, steps, prob.lm, prob.ep, own=sh["own"])
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     st, m = solver.backend.status()
     if st & 3:
         raise RuntimeError(f"BA reported contract violation status={st}")
 
+    info = dict(N=N, E=E, E_local=int(p.ii.shape[0]), M_local=int(p.eta.shape[0]), HW=H * W, P=prob.t1 - prob.t0,
+                chol_failed=bool(st & 4), steps=steps)
+    if not profile:
+        return dt, {}, info, prob
     # per-stage durations: HIP events on the launch stream, averaged over 5 iterations
     reset()
     solver.backend.prepare(p, prob.t0, prob.t1, sh["own"], False)
@@ -121,8 +131,7 @@ def bench_ba(args, rank, world, dev):
         solver.run(p, prob.t0, prob.t1, 2, prob.lm, prob.ep, own=sh["own"])
     barrier()
     call2_ms = (time.perf_counter() - t1) / 5 * 1e3
-    info = dict(N=N, E=E, E_local=int(p.ii.shape[0]), M_local=int(p.eta.shape[0]), HW=H * W, P=prob.t1 - prob.t0,
-                call2_ms=call2_ms, chol_failed=bool(st & 4))
+    info["call2_ms"] = call2_ms
     return dt, stages, info, prob
 
 
@@ -260,9 +269,57 @@ def cpu_baseline(budget_s=15.0):
     more = int(min(16, budget_s / max(t1, 1e-3)))
     if more >= 2:
         iters, dt = more, run(more)
-    return dict(value=iters / dt, unit="BA iters/s", cores=cores, kind="port",
-                sample=f"{iters} Gauss-Newton iteration(s) of the full 256-keyframe/2000-edge 48x64 graph, "
-                       f"fp64 oracle (OpenMP over edges and depth frames), {dt:.1f} s")
+    out = dict(value=iters / dt, unit="BA iters/s", cores=cores, kind="port", cpu_model=cpu_model(),
+               sample=f"{iters} Gauss-Newton iteration(s) of the full 256-keyframe/2000-edge 48x64 graph, "
+                      f"fp64 oracle (OpenMP over edges and depth frames), {dt:.1f} s")
+    # single thread, bounded: one iteration of the 64-keyframe / 512-edge graph (configs[1])
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        p2 = synth.make_config("cfg2")
+        t0 = time.perf_counter()
+        oracle.ba(p2.poses, p2.disps, p2.intrinsics, p2.disps_sens, p2.targets, p2.weights, p2.eta, p2.ii, p2.jj,
+                  p2.t0, p2.t1, 1, p2.lm, p2.ep, False)
+        d1 = time.perf_counter() - t0
+        gomp.omp_set_num_threads(cores)
+        out["single_thread"] = dict(value=1.0 / d1, unit="BA iters/s", cores=1,
+                                    sample=f"1 iteration of the 64-keyframe/512-edge 48x64 graph (configs[1]), {d1:.1f} s")
+    except Exception as e:  # pragma: no cover
+        log("single-thread baseline skipped:", e)
+    # correlation lookups on the CPU: the numpy restatement (one thread), 2 edges, 4 levels each
+    try:
+        rng = np.random.default_rng(0)
+        H, W = 48, 64
+        c = np.stack([rng.uniform(0, W, (2, H, W)), rng.uniform(0, H, (2, H, W))], 1).astype(np.float32)
+        vols = [rng.normal(0, 1, (2, H, W, H >> l, W >> l)).astype(np.float16) for l in range(4)]
+        t0 = time.perf_counter()
+        for l in range(4):
+            oracle.corr_index_forward(vols[l], c / 2 ** l, 3)
+        dv = time.perf_counter() - t0
+        f1 = rng.normal(0, 1, (1, H, W, 128)).astype(np.float32)
+        f2 = [rng.normal(0, 1, (1, H >> l, W >> l, 128)).astype(np.float32) for l in range(4)]
+        ca = np.ascontiguousarray(c[:1].transpose(0, 2, 3, 1))[:, None]
+        t0 = time.perf_counter()
+        for l in range(4):
+            oracle.altcorr_forward(f1, f2[l], ca / 2 ** l, 3, acc_dtype=np.float64)
+        da = time.perf_counter() - t0
+        out["corr"] = dict(volume_fp16_gpix_per_s=2 * H * W / dv / 1e9, altcorr_gpix_per_s=H * W / da / 1e9, cores=1,
+                           kind="port", sample=f"numpy restatement: volume lookup 2 edges x 4 levels {dv:.2f} s, "
+                                               f"alt-corr 1 edge x 4 levels {da:.2f} s")
+    except Exception as e:  # pragma: no cover
+        log("corr cpu baseline skipped:", e)
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -273,14 +330,49 @@ def main():
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
+    # rehearsal of the multi-rank path on a one-GPU box: all ranks on device 0, gloo instead of RCCL, and the
+    # cooperative solver launch (two ranks' spinning grids cannot both be resident on one GPU).  Not a measurement.
+    share = os.environ.get("DROID_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local = 0
+        os.environ.setdefault("DROID_CHOL_COOPERATIVE", "1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    dt, stages, info, prob = bench_ba(args, rank, world, dev)
+    from droid_backends import synth
+    E_total = args.edges_total if args.edges_total > 0 else (2000 if world == 1 else 8000)
+    seed = synth.CONFIG_SEEDS["cfg3"] if E_total == 2000 else synth.CONFIG_SEEDS["cfg4"]
+    dt, stages, info, prob = bench_ba(args, rank, world, dev, args.keyframes, E_total, seed=seed)
+    extra = {}
+    if not args.no_extra:
+        if world == 1:
+            # the other BASELINE configs on this GPU (parity of each: tests/test_gpu_ba*.py, test_gpu_baseline_shapes.py)
+            cfgs = {}
+            for name, tested in (("cfg2", "test_gpu_ba.py::test_ba_cfg2_64kf_512e"),
+                                 ("cfg4", "test_gpu_ba_full.py::test_cfg4_256kf_8000e_matches_oracle (unsharded), "
+                                          "test_gpu_sharded.py[cfg4like] (2 ranks)"),
+                                 ("cfg5", "test_gpu_ba_full.py::test_cfg5_stereo_96x128_matches_oracle")):
+                Nc, Ec, Hc, Wc, rc, stc, lmc, epc = synth.CONFIGS[name]
+                d2, _, inf2, _ = bench_ba(args, rank, world, dev, Nc, Ec, Hc, Wc, stc, lmc, epc, synth.CONFIG_SEEDS[name],
+                                          steps=8, profile=False)
+                cfgs[name] = dict(keyframes=Nc, edges=Ec, H=Hc, W=Wc, stereo=stc, iters_per_sec=8 / d2,
+                                  ms_per_iteration=d2 / 8 * 1e3, parity_tested=tested, chol_failed=inf2["chol_failed"])
+                torch.cuda.empty_cache()
+            extra["configs_1gpu"] = cfgs
+        else:
+            Ew = args.edges_per_gpu * world
+            dw, _, infw, _ = bench_ba(args, rank, world, dev, args.keyframes, Ew, seed=synth.CONFIG_SEEDS["cfg3"], profile=False)
+            extra["weak_scaling"] = dict(edges_per_gpu=args.edges_per_gpu, edges_total=Ew, raw_iters_per_sec=args.steps / dw,
+                                         value_2000_edge_equivalents=args.steps / dw * Ew / 2000.0,
+                                         ms_per_step=dw / args.steps * 1e3, scaling="weak")
+            torch.cuda.empty_cache()
     corr = None
     if not args.no_corr:
         try:
@@ -292,7 +384,7 @@ def main():
         import torch.distributed as dist
         if corr is not None:  # edges are independent: aggregate rate = sum over ranks
             t = torch.tensor([corr["volume_fp16"]["gpix_per_s"], corr["altcorr_fp32"]["gpix_per_s"]],
-                             dtype=torch.float64, device=dev)
+                             dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t)
             corr["volume_fp16"]["gpix_per_s_all_ranks"] = float(t[0])
             corr["altcorr_fp32"]["gpix_per_s_all_ranks"] = float(t[1])
@@ -306,11 +398,14 @@ def main():
         # launch from the committed rocprofv3 --pmc passes of this same command (profiles/).
         HW, E_l, M_l, Nk, P = info["HW"], info["E_local"], info["M_local"], info["N"], info["P"]
         n = 6 * P
-        pmc = {}
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        except Exception:
-            pass
+        pmc, pmc_src = {}, None
+        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                pmc_src = "profiles/" + name
+                break
+            except Exception:
+                continue
 
         def traffic(kernel):
             k = pmc.get(kernel)
@@ -318,15 +413,20 @@ def main():
                 return None
             return (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
 
+        # NOT measured in this run: PMC counters need their own rocprofv3 passes (tools/collect_profiles.sh)
+        tsrc = (pmc_src + " (rocprofv3 --pmc passes of this command at the commit that wrote the file; "
+                          "FETCH_SIZE x2 per the gfx950 128-byte-request correction, calibrated in "
+                          "profiles/r02_gather16_calibration.txt)") if pmc_src else None
+
         def hbm(kernel, stage, alg_bytes, note):
             a = alg_bytes / (stages[stage] * 1e-3) / 1e9
             return dict(kernel=kernel, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=a / HBM_PEAK_GBS, traffic=traffic(kernel), algorithmic_bytes=alg_bytes, note=note)
+                        frac=a / HBM_PEAK_GBS, traffic=traffic(kernel), traffic_source=tsrc, algorithmic_bytes=alg_bytes, note=note)
 
         def flop(kernel, stage, flops, peak, note):
             a = flops / (stages[stage] * 1e-3) / 1e12
             return dict(kernel=kernel, bound="mfma", achieved=a, peak=peak, unit="TFLOP/s", frac=a / peak,
-                        traffic=traffic(kernel), algorithmic_flops=flops, note=note)
+                        traffic=traffic(kernel), traffic_source=tsrc, algorithmic_flops=flops, note=note)
 
         deg = np.bincount(prob.ii, minlength=Nk)  # Schur GEMM, symmetric minimum
         nk = deg + 1
@@ -354,18 +454,21 @@ def main():
         line = {
             "metric": "BA update iters/sec (2000-edge equivalents; 256 keyframes, 48x64)",
             "value": value, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
+            "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{info['N']}-keyframe / {info['E']}-edge global BA, 48x64, t0=1, lm=1e-5 ep=1e-2"
-                                   + (" (BASELINE configs[2])" if world == 1 else
-                                      f", edges sharded by source frame over {world} GPUs, 1 all-reduce/iter"),
-                       "raw_iters_per_sec": raw, "edges_total": info["E"], "edges_per_gpu": args.edges_per_gpu,
+                                   + (" (BASELINE configs[2])" if (world == 1 and info["E"] == 2000) else
+                                      (" (BASELINE configs[3])" if info["E"] == 8000 else "")
+                                      + (f", edges sharded by source frame over {world} GPUs, 1 all-reduce/iter" if world > 1 else "")),
+                       "raw_iters_per_sec": raw, "edges_total": info["E"], "edges_per_gpu": info["E"] / world,
                        "ms_per_call_iterations2": info["call2_ms"], "stage_ms": stages,
                        "solve": "fp64 dense Cholesky on device", "chol_failed": info["chol_failed"]},
             "roofline": roof,
             "rooflines": kernels,
             "cpu_baseline": cpu,
             "corr": corr,
+            "extra": extra,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+
 #include "../../include/droid_backends_hip.h"
 #include "ba_internal.hpp"
 
@@ -45,6 +48,15 @@ void launch_reproject_motion(const float* poses, const float* disps, const float
 using namespace droid;
 
 static thread_local char g_err[512] = "";
+
+// workspace -> host-visible status words (droid_ba_attach_status_mirror)
+static std::map<const void*, int*> g_mirror;
+static std::mutex g_mirror_mu;
+static int* mirror_of(const void* ws) {
+  std::lock_guard<std::mutex> lock(g_mirror_mu);
+  auto it = g_mirror.find(ws);
+  return it == g_mirror.end() ? nullptr : it->second;
+}
 
 static int fail(int code, const char* fmt, const char* what) {
   snprintf(g_err, sizeof(g_err), fmt, what);
@@ -206,7 +218,8 @@ int droid_ba_solve_update(float* poses, float* disps, const float* intrinsics, c
   if (!preset) (void)hipMemsetAsync(v.hdr + HDR_CHOL_FAIL, 0, sizeof(int), s);
   launch_chol_solve(v.sys, v.n, v.ld, (double)lm, (double)ep, v.xsol, v.hdr + HDR_CHOL_FAIL, v.bs_flags, v.ldiag, s,
                     preset);
-  launch_update(v, poses, disps, intrinsics, weights, ii, jj, v.xsol, dx_out, dz_out, motion_only != 0, s);
+  launch_update(v, poses, disps, intrinsics, weights, ii, jj, v.xsol, dx_out, dz_out, motion_only != 0, s,
+                mirror_of(workspace));
   return check_hip("ba_solve_update");
 }
 
@@ -260,9 +273,9 @@ int droid_ba_profile_iteration(float* poses, float* disps, const float* intrinsi
     (void)hipMemsetAsync(v.bs_flags, 0xFF, sizeof(int) * chol_flag_words(v.n), s);
     (void)hipMemsetAsync(v.ldiag + chol_lfin_offset(v.n), 0xFF, sizeof(double) * chol_tiles(v.n) * CHOL_NB * CHOL_NB, s);
   }
-  launch_chol_factor(v.sys, v.n, v.ld, (double)lm, (double)ep, v.hdr + HDR_CHOL_FAIL, v.bs_flags, v.ldiag, s);
+  const bool single = launch_chol_factor(v.sys, v.n, v.ld, (double)lm, (double)ep, v.hdr + HDR_CHOL_FAIL, v.bs_flags, v.ldiag, s);
   (void)hipEventRecord(ev[5], s);
-  launch_chol_backsolve(v.sys, v.n, v.ld, v.xsol, v.bs_flags, v.ldiag, v.hdr + HDR_CHOL_FAIL, s);
+  launch_chol_backsolve(v.sys, v.n, v.ld, v.xsol, v.bs_flags, v.ldiag, v.hdr + HDR_CHOL_FAIL, s, single);
   (void)hipEventRecord(ev[6], s);
   launch_update(v, poses, disps, intrinsics, weights, ii, jj, v.xsol, nullptr, nullptr, motion_only != 0, s);
   (void)hipEventRecord(ev[7], s);
@@ -297,6 +310,14 @@ int droid_ba_status(const void* workspace, void* stream, int* status_out, int* d
   }
   if (status_out) *status_out = hdr[HDR_STATUS];
   if (depth_slots_out) *depth_slots_out = hdr[HDR_M];
+  return DROID_OK;
+}
+
+int droid_ba_attach_status_mirror(const void* workspace, int* mirror) {
+  if (!workspace) return fail(DROID_E_ARG, "ba_attach_status_mirror: null %s", "workspace");
+  std::lock_guard<std::mutex> lock(g_mirror_mu);
+  if (mirror) g_mirror[workspace] = mirror;
+  else g_mirror.erase(workspace);
   return DROID_OK;
 }
 

@@ -30,7 +30,7 @@ __host__ __device__ inline size_t chol_lfin_offset(int n) { return 2 * chol_mbuf
 __host__ __device__ inline size_t chol_ldiag_doubles(int n) { return chol_lfin_offset(n) + chol_tiles(n) * CHOL_NB * CHOL_NB; }
 
 enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4, HDR_WORDS = 16 };
-enum { STATUS_BAD_INDEX = 1, STATUS_ETA_ROWS = 2, STATUS_CHOL_FAIL = 4 };
+enum { STATUS_BAD_INDEX = 1, STATUS_ETA_ROWS = 2, STATUS_CHOL_FAIL = 4, STATUS_CHOL_STALL = 8 };
 
 // Plain-old-data view of the workspace, passed to kernels by value.
 struct BaView {
@@ -140,9 +140,10 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
                         const float* sens, const float* targets, const float* weights,
                         const float* eta, const int64_t* ii, const int64_t* jj, bool motion_only,
                         int stage, hipStream_t s);
+// status_mirror: optional device-visible host words {status, depth slots} written at the end of the iteration
 void launch_update(const BaView& v, float* poses, float* disps, const float* intr, const float* weights,
                    const int64_t* ii, const int64_t* jj, const double* x, float* dx_out, float* dz_out,
-                   bool motion_only, hipStream_t s);
+                   bool motion_only, hipStream_t s, int* status_mirror = nullptr);
 // In-place damped Cholesky of the lower triangle of sys ((n+1) x ld, row n = rhs) + solve -> x [n].
 // flags [chol_flag_words(n)] and ldiag [chol_ldiag_doubles(n)]: scratch of the single-launch factorisation
 // (null: one launch per block column).  launch_chol_solve presets x and flags itself unless told that it has
@@ -150,9 +151,10 @@ void launch_update(const BaView& v, float* poses, float* disps, const float* int
 void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
                        int* flags, double* ldiag, hipStream_t s, bool preset_done = false);
 
-void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag, int* flags,
+// launch_chol_factor returns whether the single-launch kernel ran; pass that to launch_chol_backsolve
+bool launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag, int* flags,
                         double* ldiag, hipStream_t s);
 void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, double* ldiag, int* err,
-                           hipStream_t s);
+                           hipStream_t s, bool factor_single);
 
 }  // namespace droid

@@ -1240,10 +1240,21 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
 // pose retraction T <- exp(dx) T for the window (pose_retr_kernel :898-931); dx = fp32 of the fp64
 // solution, zeros when the factorisation failed (:1202-1210)
 __global__ void ba_pose_retr_kernel(BaView v, float* __restrict__ poses, const double* __restrict__ xsol,
-                                    float* __restrict__ dx_out) {
+                                    float* __restrict__ dx_out, int* __restrict__ status_mirror) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool failed = v.hdr[HDR_CHOL_FAIL] != 0;
-  if (p == 0 && failed) atomicOr(&v.hdr[HDR_STATUS], STATUS_CHOL_FAIL);
+  const int fl = v.hdr[HDR_CHOL_FAIL];  // 1 = not positive definite (dx = 0 like dk:1202-1210), 2 = stalled grid
+  const bool failed = fl != 0;
+  if (p == 0) {
+    int st = v.hdr[HDR_STATUS];
+    if (failed) {
+      st |= (fl >= 2) ? STATUS_CHOL_STALL : STATUS_CHOL_FAIL;
+      atomicOr(&v.hdr[HDR_STATUS], (fl >= 2) ? STATUS_CHOL_STALL : STATUS_CHOL_FAIL);
+    }
+    if (status_mirror) {  // host-visible copy: the wrapper reads it at its next call without synchronising
+      __hip_atomic_store(status_mirror + 1, v.hdr[HDR_M], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(status_mirror, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   if (p >= v.P) return;
   const int k = v.t0 + p;
   float xi[6], t[3], q[4], tn[3], qn[4];
@@ -1333,11 +1344,11 @@ void launch_build(const BaView& v, const float* poses, const float* disps, const
 
 void launch_update(const BaView& v, float* poses, float* disps, const float* intr, const float* weights,
                    const int64_t* ii, const int64_t* jj, const double* x, float* dx_out, float* dz_out,
-                   bool motion_only, hipStream_t s) {
+                   bool motion_only, hipStream_t s, int* status_mirror) {
   if (!motion_only && v.M > 0)
     hipLaunchKernelGGL(ba_backsub_kernel, dim3(v.M, (v.HW + 256 * BSUB_PPT - 1) / (256 * BSUB_PPT)), dim3(256), 0, s, v, poses, disps,
                        intr, weights, ii, jj, x, dz_out);
-  hipLaunchKernelGGL(ba_pose_retr_kernel, dim3((v.P + 63) / 64), dim3(64), 0, s, v, poses, x, dx_out);
+  hipLaunchKernelGGL(ba_pose_retr_kernel, dim3((v.P + 63) / 64), dim3(64), 0, s, v, poses, x, dx_out, status_mirror);
 }
 
 }  // namespace droid

@@ -22,6 +22,7 @@
 //     `chol_step_kernel` (one launch per block column, same body) is the fallback;
 //   * `chol_backsolve_persistent_kernel`: the backward substitution in one launch, x itself is the hand-off flag.
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 #include <cstdint>
 #include <cstdlib>
@@ -280,7 +281,7 @@ __device__ __forceinline__ void wave_potrf16(lds_f64* Lb, lds_f64* Wl, const lds
     }
   }
   const bool bad = !(ylast > 0.0 && ylast < 1.0e300);  // NaN (non-positive pivot somewhere) or overflow
-  if (lane == 0 && bad && report) *fail = 1;
+  if (lane == 0 && bad && report) atomicMax(fail, 1);
   __builtin_amdgcn_s_setprio(0);
 }
 
@@ -413,7 +414,7 @@ __device__ __forceinline__ void load_strip64(lds_f64* __restrict__ dst, const gb
     if (there) break;
     if (++spins > CFP_SPIN_LIMIT || ((spins & 255) == 0 && cfp_load(abortf) == 1)) {
       cfp_store(abortf, 1);  // never hang: the caller sees `abort` before its next tile, the result is discarded
-      atomicExch(fail, 1);
+      atomicMax(fail, 2);    // 2 = stalled grid (not a numerical failure): reported as STATUS_CHOL_STALL
       break;
     }
     __builtin_amdgcn_s_sleep(1);
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
           s_abort = ok ? 0 : 1;
           if (!ok) {
             cfp_store(abortf, 1);
-            atomicExch(fail, 1);
+            atomicMax(fail, 2);
           }
         }
       }
@@ -1070,7 +1071,7 @@ __global__ __launch_bounds__(256) void chol_backsolve_persistent_kernel(
         if (__double_as_longlong(xv) != BSP_SENTINEL) break;
         if (++spins > (1 << 22)) {  // cannot happen with a resident grid; never hang the GPU
           dead = 1;
-          atomicExch(err, 1);
+          atomicMax(err, 2);
           xv = 0.0;
           break;
         }
@@ -1211,9 +1212,49 @@ static bool chol_single_launch(const double* sys, int n, int ld, const int* flag
          chol_tiles(n) <= (size_t)10 * chol_resident_workgroups();
 }
 
-void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag, int* flags,
+// ---- residency of the single-launch kernels ------------------------------------------------------------------
+// Both persistent kernels spin across workgroups, so their whole grid must be resident.  A plain launch gives that
+// whenever nothing else holds the CUs for good: ordinary kernels of other streams only delay the dispatch of the
+// remaining workgroups.  The one thing that can deadlock is ANOTHER spinning grid:
+//   * within a process (two streams / threads calling `ba`): serialised here.  When a persistent launch arrives on
+//     a different stream than the previous one, an event recorded on the previous stream is waited for first, so
+//     two such grids never overlap.  Single-stream use (the SLAM loop) never records or waits.
+//   * across processes sharing one GPU: DROID_CHOL_COOPERATIVE=1 launches through hipLaunchCooperativeKernel,
+//     which admits the grid only if it can be resident and runs one cooperative grid at a time (+19 us per launch,
+//     tools/micro/coop_launch.hip, which is why it is not the default); if the launch is refused the per-step
+//     kernels run instead.  A stall that happens anyway ends in the bounded spins: fail flag = 2, reported as
+//     STATUS_CHOL_STALL (an error, unlike the numerical STATUS_CHOL_FAIL whose dx = 0 is the reference's behaviour).
+struct PersistState {
+  hipStream_t last = nullptr;
+  hipEvent_t ev = nullptr;
+  bool any = false;
+};
+static PersistState g_persist[64];
+static std::mutex g_persist_mu;
+
+static void persist_enter(hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+  std::lock_guard<std::mutex> lock(g_persist_mu);
+  PersistState& st = g_persist[dev];
+  if (st.any && st.last != s) {
+    if (!st.ev && hipEventCreateWithFlags(&st.ev, hipEventDisableTiming) != hipSuccess) st.ev = nullptr;
+    if (st.ev && hipEventRecord(st.ev, st.last) == hipSuccess) (void)hipStreamWaitEvent(s, st.ev, 0);
+    (void)hipGetLastError();  // a destroyed previous stream must not poison this call
+  }
+  st.last = s;
+  st.any = true;
+}
+
+static bool chol_cooperative() {
+  static const bool on = (getenv("DROID_CHOL_COOPERATIVE") != nullptr && atoi(getenv("DROID_CHOL_COOPERATIVE")) != 0);
+  return on;
+}
+
+// returns true when the single-launch kernel ran (the back-substitution may then use what it left in `ldiag`)
+bool launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag, int* flags,
                         double* ldiag, hipStream_t s) {
-  if (n <= 0) return;
+  if (n <= 0) return false;
   const int nb = (n + NB - 1) / NB;        // block columns
   const int nrb = (n + 1 + NB - 1) / NB;   // block rows (row n = rhs)
   if (chol_single_launch(sys, n, ld, flags, ldiag)) {
@@ -1223,25 +1264,46 @@ void launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* f
     static const int env_cap = getenv("DROID_CHOL_GRID") ? atoi(getenv("DROID_CHOL_GRID")) : 0;  // diagnostics
     if (env_cap >= 8 && env_cap < cap) cap = env_cap;
     const int grid = total < cap ? total : cap;
-    hipLaunchKernelGGL(chol_factor_persistent_kernel, dim3(grid), dim3(512), 0, s, sys, n, ld, fail_flag, lm,
-                       ep, flags, ldiag);
-    return;
+    persist_enter(s);
+    if (chol_cooperative()) {
+      void* args[] = {&sys, &n, &ld, &fail_flag, &lm, &ep, &flags, &ldiag};
+      if (hipLaunchCooperativeKernel((const void*)chol_factor_persistent_kernel, dim3(grid), dim3(512), args, 0, s) == hipSuccess)
+        return true;
+      (void)hipGetLastError();  // refused (grid cannot be resident now): per-step kernels below
+    } else {
+      hipLaunchKernelGGL(chol_factor_persistent_kernel, dim3(grid), dim3(512), 0, s, sys, n, ld, fail_flag, lm,
+                         ep, flags, ldiag);
+      return true;
+    }
   }
   for (int k = -1; k + 1 < nb; k++)         // launch k finishes panel k+1; launch -1 also damps
     hipLaunchKernelGGL(chol_step_kernel, dim3(nrb - k - 1, k < 0 ? 2 : nb - k - 1), dim3(512), 0, s, sys, n,
                        ld, k, fail_flag, lm, ep);
+  return false;
 }
 
 void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, double* ldiag, int* err,
-                           hipStream_t s) {
+                           hipStream_t s, bool factor_single) {
   const int nb = (n + NB - 1) / NB;
   if (flags != nullptr && nb >= 2 && nb <= BSP_MAX_BLOCKS) {
-    if (chol_single_launch(sys, n, ld, flags, ldiag))
-      hipLaunchKernelGGL(chol_backsolve_persistent_kernel<true>, dim3(nb), dim3(256), 0, s, sys, n, ld, x, err, ldiag);
-    else
-      hipLaunchKernelGGL(chol_backsolve_persistent_kernel<false>, dim3(nb), dim3(256), 0, s, sys, n, ld, x, err,
-                         nullptr);
-    return;
+    persist_enter(s);
+    double* ld_arg = factor_single ? ldiag : nullptr;
+    const void* fn = factor_single ? (const void*)chol_backsolve_persistent_kernel<true>
+                                   : (const void*)chol_backsolve_persistent_kernel<false>;
+    if (chol_cooperative()) {
+      void* args[] = {&sys, &n, &ld, &x, &err, &ld_arg};
+      if (hipLaunchCooperativeKernel(fn, dim3(nb), dim3(256), args, 0, s) == hipSuccess) return;
+      (void)hipGetLastError();
+      if (factor_single) {  // `x` carries the sentinel preset: the per-step kernels below overwrite all of it
+      }
+    } else {
+      if (factor_single)
+        hipLaunchKernelGGL(chol_backsolve_persistent_kernel<true>, dim3(nb), dim3(256), 0, s, sys, n, ld, x, err, ldiag);
+      else
+        hipLaunchKernelGGL(chol_backsolve_persistent_kernel<false>, dim3(nb), dim3(256), 0, s, sys, n, ld, x, err,
+                           nullptr);
+      return;
+    }
   }
   for (int k = nb - 1; k >= 0; k--) {
     const int c0 = k * NB;
@@ -1256,8 +1318,8 @@ void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double*
                        int* flags, double* ldiag, hipStream_t s, bool preset_done) {
   if (n <= 0) return;
   if (preset_done) {
-    launch_chol_factor(sys, n, ld, lm, ep, fail_flag, flags, ldiag, s);
-    launch_chol_backsolve(sys, n, ld, x, flags, ldiag, fail_flag, s);
+    const bool single = launch_chol_factor(sys, n, ld, lm, ep, fail_flag, flags, ldiag, s);
+    launch_chol_backsolve(sys, n, ld, x, flags, ldiag, fail_flag, s, single);
     return;
   }
   if (ldiag)  // hand-over slots of the panel tiles: data-tagged, 0xFF bytes = not there yet
@@ -1271,8 +1333,8 @@ void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double*
     (void)hipMemsetAsync(x, 0xFF, xbytes, s);
     if (flags) (void)hipMemsetAsync(flags, 0xFF, fbytes, s);
   }
-  launch_chol_factor(sys, n, ld, lm, ep, fail_flag, flags, ldiag, s);
-  launch_chol_backsolve(sys, n, ld, x, flags, ldiag, fail_flag, s);
+  const bool single = launch_chol_factor(sys, n, ld, lm, ep, fail_flag, flags, ldiag, s);
+  launch_chol_backsolve(sys, n, ld, x, flags, ldiag, fail_flag, s, single);
 }
 
 #ifdef CHOL_STAMPS

@@ -22,11 +22,30 @@ __all__ = ["ba", "frame_distance", "projmap", "depth_filter", "iproj", "altcorr_
            "altcorr_pyramid_forward", "reproject", "motion_features"]  # the last three are additions
 
 _DT = {torch.float16: _lib.DROID_F16, torch.float32: _lib.DROID_F32, torch.float64: _lib.DROID_F64}
-_workspaces = {}
+_workspaces = {}   # (device index, stream handle) -> _Workspace
 
-# DROID_HIP_CHECK=1: read the BA status word back after every call (one sync) and raise on
-# contract violations; default: errors surface at the next call's check (no host sync at all).
+# Contract violations only a kernel can see (edge index outside the buffer, eta rows != depth slots, a stalled
+# solver grid) are written to a status word.  DROID_HIP_CHECK=1: read it back after every call (one sync) and
+# raise.  Default: no sync -- the last kernel of a call also writes the word to page-locked host memory, and the
+# NEXT `ba` call on the same (device, stream) raises if the previous one had reported a violation by then.
 _SYNC_CHECK = _os.environ.get("DROID_HIP_CHECK", "0") == "1"
+
+
+class _Workspace:
+    """Grow-only scratch of the `ba` calls of one (device, stream) + the host mirror of its status word."""
+
+    def __init__(self):
+        self.buf = None
+        self.mirror = torch.zeros(2, dtype=torch.int32).pin_memory()
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes:
+            lib = _lib.load()
+            if self.buf is not None:
+                lib.droid_ba_attach_status_mirror(self.buf.data_ptr(), None)
+            self.buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+            _lib.check(lib.droid_ba_attach_status_mirror(self.buf.data_ptr(), self.mirror.data_ptr()), "ba (status mirror)")
+        return self.buf
 
 
 def _check_input(x, name):
@@ -37,6 +56,19 @@ def _check_input(x, name):
         raise RuntimeError(f"{name} must be a HIP (cuda) tensor: droid_backends has no CPU path")
 
 
+def _check_index(x, name):
+    """The kernels read edge / frame indices as int64 (torch.long, like the reference's accessors)."""
+    _check_input(x, name)
+    if x.dtype != torch.int64:
+        raise RuntimeError(f"{name} must be int64 (torch.long), got {x.dtype}")
+
+
+def _check_f32(x, name):
+    _check_input(x, name)
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {x.dtype}")
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -45,37 +77,48 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _workspace(nbytes, device):
-    """Grow-only per-device scratch buffer (kept across calls: no allocation on the hot path)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+def _ws_key(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return (idx, torch.cuda.current_stream(idx).cuda_stream)
+
+
+def _workspace_obj(device):
+    key = _ws_key(device)
     ws = _workspaces.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+    if ws is None:
+        ws = _workspaces[key] = _Workspace()
     return ws
 
 
 def ba_status(workspace=None):
-    """(status, depth_slots) of the last `ba` on the current device (blocking read)."""
+    """(status, depth_slots) of the last `ba` on the current device and stream (blocking read)."""
     import ctypes
     lib = _lib.load()
+    obj = None
     if workspace is None:
-        workspace = _workspaces.get(torch.cuda.current_device())
+        dev = torch.cuda.current_device()
+        obj = _workspaces.get((dev, torch.cuda.current_stream(dev).cuda_stream))
+        workspace = obj.buf if obj is not None else None
     if workspace is None:
         return 0, 0
     st, m = ctypes.c_int(0), ctypes.c_int(0)
     _lib.check(lib.droid_ba_status(workspace.data_ptr(), _stream(), ctypes.byref(st), ctypes.byref(m)), "ba_status")
+    if obj is not None:
+        obj.mirror.zero_()   # the caller has seen this call's status: the next `ba` does not raise it again
     return st.value, m.value
 
 
 _STATUS_TEXT = {1: "edge index outside the pose buffer", 2: "eta rows != number of depth slots "
-                "|unique(ii) U [t0,t1)|", 4: "Cholesky failed (dx = 0)"}
+                "|unique(ii) U [t0,t1)|", 4: "Cholesky failed (dx = 0)",
+                8: "the single-launch solver stalled: another spinning grid held the GPU (dx = 0); "
+                   "set DROID_CHOL_COOPERATIVE=1 or DROID_CHOL_MULTI_LAUNCH=1 when several processes share the GPU"}
 
 
-def _raise_on_status(st, m):
+def _raise_on_status(st, m, when=""):
+    # bit 4 (not positive definite => dx = 0) is the reference's silent behaviour (droid_kernels.cu:1207-1210)
     bad = [txt for bit, txt in _STATUS_TEXT.items() if (st & bit) and bit != 4]
     if bad:
-        raise RuntimeError("droid_backends.ba: " + "; ".join(bad) + f" (device counted {m} depth slots)")
+        raise RuntimeError(f"droid_backends.ba{when}: " + "; ".join(bad) + f" (device counted {m} depth slots)")
 
 
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations,
@@ -112,7 +155,13 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     nbytes = lib.droid_ba_workspace_bytes(E, nbuf, H, W, t0, t1, M)
     if nbytes == 0:
         raise RuntimeError("droid_backends.ba: bad sizes / window")
-    ws = _workspace(nbytes, dev)
+    wso = _workspace_obj(dev)
+    prev = int(wso.mirror[0])   # what the previous call on this stream reported (plain host read, no sync)
+    if prev & ~4:
+        prev_m = int(wso.mirror[1])
+        wso.mirror.zero_()
+        _raise_on_status(prev, prev_m, " (previous call on this stream)")
+    ws = wso.get(nbytes, dev)
     dx = torch.empty((max(P, 0), 6), dtype=torch.float32, device=dev)
     dz = torch.empty((M, H * W), dtype=torch.float32, device=dev)
     rc = lib.droid_ba(poses.data_ptr(), disps.data_ptr(), intrinsics.data_ptr(), disps_sens.data_ptr(),
@@ -121,15 +170,19 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
                       dz.data_ptr() if M > 0 else None, ws.data_ptr(), ws.numel(), _stream())
     _lib.check(rc, "ba")
     if _SYNC_CHECK:
-        _raise_on_status(*ba_status(ws))
+        st = ba_status(ws)
+        wso.mirror.zero_()
+        _raise_on_status(*st)
     return [dx, dz]
 
 
 def frame_distance(poses, disps, intrinsics, ii, jj, beta):
     """droid.cpp:120-136 -> frame_distance_cuda droid_kernels.cu:1438-1460."""
     lib = _lib.load()
-    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
-        _check_input(x, n)
+    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics")):
+        _check_f32(x, n)
+    _check_index(ii, "ii")
+    _check_index(jj, "jj")
     nbuf, H, W = disps.shape
     nbuf = min(int(nbuf), int(poses.shape[0]))
     E = int(ii.shape[0])
@@ -143,8 +196,10 @@ def frame_distance(poses, disps, intrinsics, ii, jj, beta):
 def projmap(poses, disps, intrinsics, ii, jj):
     """droid.cpp:139-154 -> projmap_cuda droid_kernels.cu:1463-1488."""
     lib = _lib.load()
-    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
-        _check_input(x, n)
+    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics")):
+        _check_f32(x, n)
+    _check_index(ii, "ii")
+    _check_index(jj, "jj")
     nbuf, H, W = disps.shape
     nbuf = min(int(nbuf), int(poses.shape[0]))
     E = int(ii.shape[0])
@@ -208,8 +263,9 @@ def motion_features(poses, disps, intrinsics, ii, jj, target):
 def depth_filter(poses, disps, intrinsics, ix, thresh):
     """droid.cpp:220-234 -> depth_filter_cuda droid_kernels.cu:1491-1515."""
     lib = _lib.load()
-    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ix, "ix"), (thresh, "thresh")):
-        _check_input(x, n)
+    for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (thresh, "thresh")):
+        _check_f32(x, n)
+    _check_index(ix, "ix")
     nbuf, H, W = disps.shape
     nbuf = min(int(nbuf), int(poses.shape[0]))
     num = int(ix.shape[0])
@@ -224,7 +280,7 @@ def iproj(poses, disps, intrinsics):
     """droid.cpp:157-166 -> iproj_cuda droid_kernels.cu:1518-1541."""
     lib = _lib.load()
     for x, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics")):
-        _check_input(x, n)
+        _check_f32(x, n)
     nm, H, W = disps.shape
     points = torch.empty((nm, H, W, 3), dtype=torch.float32, device=disps.device)
     _lib.check(lib.droid_iproj(poses.data_ptr(), disps.data_ptr(), intrinsics.data_ptr(), nm, H, W,
@@ -258,7 +314,7 @@ def corr_index_backward(volume, coords, corr_grad, radius):
     """droid.cpp:180-191 -> corr_index_cuda_backward correlation_kernels.cu:157-185."""
     lib = _lib.load()
     _check_input(volume, "volume")
-    _check_input(coords, "coords")
+    _check_f32(coords, "coords")
     _check_input(corr_grad, "corr_grad")
     B, H1, W1, H2, W2 = volume.shape
     if corr_grad.dtype != volume.dtype:

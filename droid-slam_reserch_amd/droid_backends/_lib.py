@@ -18,7 +18,8 @@ SYMBOLS = [
     "droid_corr_index_forward", "droid_corr_index_backward",
     "droid_altcorr_forward", "droid_altcorr_backward", "droid_altcorr_pyramid_forward",
     "droid_ba_workspace_bytes", "droid_ba", "droid_ba_prepare", "droid_ba_build",
-    "droid_ba_solve_update", "droid_ba_profile_iteration", "droid_ba_system", "droid_ba_status", "droid_chol_solve", "droid_chol_scratch_doubles", "droid_reproject_motion",
+    "droid_ba_solve_update", "droid_ba_profile_iteration", "droid_ba_system", "droid_ba_status",
+    "droid_ba_attach_status_mirror", "droid_chol_solve", "droid_chol_scratch_doubles", "droid_reproject_motion",
     "droid_frame_distance", "droid_projmap", "droid_iproj", "droid_depth_filter",
 ]
 
@@ -63,6 +64,7 @@ def load() -> ctypes.CDLL:
     lib.droid_ba_system.argtypes = [vp] + [c_int] * 7 + [ctypes.POINTER(sz)]
     lib.droid_ba_system.restype = vp
     lib.droid_ba_status.argtypes = [vp, vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    lib.droid_ba_attach_status_mirror.argtypes = [vp, vp]
     lib.droid_chol_solve.argtypes = [vp, vp, vp, c_int, vp, vp, vp]
     lib.droid_reproject_motion.argtypes = [vp, vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]
     lib.droid_chol_scratch_doubles.argtypes = [c_int]

@@ -107,7 +107,7 @@ int droid_ba(float *poses, float *disps, const float *intrinsics, const float *d
  * droid_ba_prepare: once per call -- depth-slot table, CSR of edges by source frame.
  * droid_ba_build:   one linearisation: writes this rank's contribution to the reduced camera
  *                   system into the workspace: S = [ A - E C^-1 E^T ; b^T ] as a dense fp64
- *                   row-major matrix of 6P+1 rows with row pitch ld = roundup8(6P+1), lower
+ *                   row-major matrix of 6P+1 rows with row pitch ld = roundup16(6P+1), lower
  *                   triangle valid, row 6P = rhs, no damping yet.  droid_ba_system() returns its device address so that the
  *                   caller can all-reduce (sum) it over ranks (RCCL) before the solve.
  * droid_ba_solve_update: damping (diag += ep + lm*diag), Cholesky, solve, depth
@@ -146,8 +146,22 @@ double *droid_ba_system(void *workspace, int E, int nbuf, int H, int W, int t0, 
                         size_t *n_elements);
 
 /* Blocking read of the workspace status word: 0 ok; bit0 index out of range; bit1 eta rows !=
- * depth slots; bit2 Cholesky failed in the last solve (dx = 0, like droid_kernels.cu:1207-1210). */
+ * depth slots; bit2 Cholesky failed in the last solve (not positive definite: dx = 0, like
+ * droid_kernels.cu:1207-1210 -- the reference's behaviour, not an error); bit3 the single-launch solver's
+ * grid stalled (another spinning grid of a different PROCESS held the CUs; dx = 0; an error: run such
+ * deployments with DROID_CHOL_COOPERATIVE=1 or DROID_CHOL_MULTI_LAUNCH=1). */
 int droid_ba_status(const void *workspace, void *stream, int *status_out, int *depth_slots_out);
+
+/* Non-blocking error reporting: `mirror` points to 2 ints of page-locked host memory that the device can
+ * address (hipHostMalloc / torch pin_memory).  Every droid_ba_solve_update on this workspace then ends by
+ * writing {status word, depth slots} there (system-scope stores by the last kernel of the iteration), so the
+ * host can inspect the outcome of the PREVIOUS call whenever it likes without synchronising the stream.
+ * mirror = NULL detaches.  The registration is host-side (keyed by the workspace address).
+ *
+ * Preconditions of the phase API on one workspace: droid_ba_build and droid_ba_solve_update alternate on ONE
+ * stream (build presets the solver scratch that solve_update consumes); concurrent `ba` calls need separate
+ * workspaces (droid_backends keeps one per (device, stream)). */
+int droid_ba_attach_status_mirror(const void *workspace, int *mirror);
 
 /* Dense SPD solve used by the BA (exposed for tests): A [n,n] fp64 row-major (lower triangle
  * read, destroyed), b [n] fp64 -> x [n] fp64.  fail_flag (device int) is set to 1 when a pivot
