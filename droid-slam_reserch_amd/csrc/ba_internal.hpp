@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace droid {
 
@@ -51,6 +52,9 @@ struct BaView {
   int* ent_pose;           // [M+E] pose index in the window
   int* wk_ptr;             // [nbuf+1] scratch (slot sizes while sorting)
   int* order;              // [nbuf+1] slots sorted by descending edge count: big slots are dispatched first
+  int* gt_ptr;             // [nbuf+2] first partial-sum tile of a slot served by ba_schur2_kernel (exclusive scan)
+  double* Gpart;           // [tiles][s2_split][256] fp64 partial sums of those slots' Gram tiles, one per pixel range
+  int s2_split;            // pixel ranges per slot of ba_schur2_kernel
   float* Hpart;            // [E][nch][32] per-(edge,chunk) partial Hjj (21) + vj (6)
   float* Q;                // [M][HW] 1/C
   float* w;                // [M][HW]
@@ -96,6 +100,7 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.ent_pose = static_cast<int*>(take(sizeof(int) * ((size_t)M + E + 1)));
   v.wk_ptr = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
   v.order = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
+  v.gt_ptr = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
   v.Hpart = static_cast<float*>(take(sizeof(float) * ((size_t)E * v.nch * 32 + 32)));
   v.Q = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
   v.w = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
@@ -112,6 +117,19 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   }
   v.zpart = nullptr;
   if (v.zsplit > 1) v.zpart = static_cast<float*>(take(sizeof(float) * ((size_t)v.zsplit * M * 8 * v.HW + 64)));
+  // Schur complement of sparse slots (<= S2_MAXE edges): every (slot, pixel range) workgroup leaves the fp64
+  // Gram tiles of its E rows here; tiles(n edges) <= 1.75 n + 1 (7 row tiles of 16 at 16 edges)
+  v.s2_split = 1;
+  v.Gpart = nullptr;
+  if (M > 0) {
+    const int ptiles = (v.HW + 63) / 64;
+    static const int wg_target = getenv("DROID_S2_WGS") ? atoi(getenv("DROID_S2_WGS")) : 1536;  // diagnostics
+    int ns = wg_target / M;
+    v.s2_split = ns < 1 ? 1 : (ns > ptiles ? ptiles : ns);
+    size_t tiles = (size_t)E * 7 / 4 + (size_t)M + 1;
+    if (tiles > (size_t)28 * M) tiles = (size_t)28 * M;
+    v.Gpart = static_cast<double*>(take(sizeof(double) * (tiles * v.s2_split * 256 + 64)));
+  }
   v.sys = static_cast<double*>(take(sizeof(double) * ((size_t)(v.n + 1) * v.ld + 8)));
   v.xsol = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld + 1)));
   v.bs_flags = static_cast<int*>(take(sizeof(int) * chol_flag_words(v.n)));   // directly after xsol: one fill presets both

@@ -124,10 +124,17 @@ constexpr int SW_BIG = 512;   // rows served by the one-per-CU variant (85 entri
 // 3 = block pairs.
 // `wide` is a host-side decision (mean out-degree of the graph): sparse graphs skip the two wide
 // launches altogether and leave their few dense slots to the block-pair kernel
+constexpr int S2_MAXE = 16;   // edges per slot served by ba_schur2_kernel (class 0)
 __device__ __forceinline__ int schur_class(int rows, int nedges, int wide) {
-  if (rows <= SF_RB) return 0;
+  if (nedges <= S2_MAXE) return 0;
   if (!wide || nedges > SLOT_MAXE || rows > SW_BIG) return 3;
   return rows <= SW_MID ? 1 : 2;
+}
+// 256-double units a (class-0 slot, pixel range) leaves in v.Gpart: the 16x16 Gram tiles of its 6 nedges E rows
+// (lower triangle of row tiles) + one unit for the 6 nedges sums of E Q w
+__device__ __forceinline__ int s2_tiles(int nedges) {
+  const int ntr = (6 * nedges + 15) / 16;
+  return ntr * (ntr + 1) / 2 + 1;
 }
 
 // Loads edges [x0, x0+cnt) of slot m (cnt <= SLOT_MAXE) by the first cnt threads of the workgroup.
@@ -283,6 +290,15 @@ __global__ __launch_bounds__(1024) void ba_prep_kernel(BaView v, const int64_t* 
     }
   }
   __syncthreads();
+  // partial-sum tiles of the slots ba_schur2_kernel serves (class 0: at most S2_MAXE edges)
+  for (int m = t; m <= nbuf; m += T) v.gt_ptr[m] = 0;
+  __syncthreads();
+  for (int m = t; m < Ms; m += T) {
+    const int ne = v.seg_ptr[m + 1] - v.seg_ptr[m];
+    v.gt_ptr[m] = (ne > 0 && ne <= S2_MAXE) ? s2_tiles(ne) : 0;
+  }
+  __syncthreads();
+  block_exscan(v.gt_ptr, nbuf + 1, lds, &tot);
   // dispatch order: slots by descending edge count (ties by slot index), so that the heavy
   // workgroups of the slot-parallel kernels start first (longest-processing-time-first packing)
   for (int m = t; m < Ms; m += T) v.wk_ptr[m] = v.seg_ptr[m + 1] - v.seg_ptr[m];
@@ -310,16 +326,29 @@ __global__ __launch_bounds__(1024) void ba_prep_kernel(BaView v, const int64_t* 
 // written to v.Ebuf (row 6*entry + n; the self row Ei = -sum_e Adj^T Eij is accumulated per pixel).
 // ZSPLIT: gridDim.z workgroups share a (slot, chunk), each taking a range of the slot's edges.
 template <bool DEPTH, bool EROWS, bool ZSPLIT>
-__global__ __launch_bounds__(LIN_THREADS) void ba_lin_kernel(
+__global__ __launch_bounds__(LIN_THREADS, 3) void ba_lin_kernel(
     BaView v, const float* __restrict__ poses, const float* __restrict__ disps,
     const float* __restrict__ intrinsics, const float* __restrict__ disps_sens,
     const float* __restrict__ targets, const float* __restrict__ weights,
-    const float* __restrict__ eta, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj) {
+    const float* __restrict__ eta, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int zero_base) {
   __shared__ float red[2][LIN_THREADS / 64][32];
   __shared__ SlotMetaT<double> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HW = v.HW, W = v.W;
   const int chunk = blockIdx.y;
+  if ((int)blockIdx.x >= zero_base) {
+    // spare workgroups clear the reduced camera system for this iteration (lower triangle + rhs row: what the
+    // assemble / Schur atomics and the solve touch) -- the linearisation is VALU bound, the stores ride along,
+    // and the fill launch in front of it is gone
+    if (blockIdx.y != 0 || blockIdx.z != 0) return;
+    const int nz = (int)gridDim.x - zero_base;
+    for (int row = (int)blockIdx.x - zero_base; row <= v.n; row += nz) {
+      double2* p = reinterpret_cast<double2*>(v.sys + (size_t)row * v.ld);
+      const int n2 = (row == v.n) ? v.ld / 2 : (row + 2) / 2;   // 16-byte units covering columns 0..row
+      for (int c = tid; c < n2; c += LIN_THREADS) p[c] = make_double2(0.0, 0.0);
+    }
+    return;
+  }
   int xb, xe, f = -1, m = -1;
   if (DEPTH) {
     if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
@@ -954,6 +983,349 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Schur complement of SPARSE slots (at most S2_MAXE edges leave the frame; the sparse global / local BA
+// graphs consist of nothing else).  Same contraction as above, restructured:
+//   * only the EDGE rows E_e and the w row enter the SYRK.  The self row of the slot is a fixed linear
+//     combination of them, E_i = -sum_e Adj(T_e)^T E_e (dk:325-326, :1402), so its blocks follow from the edge
+//     blocks afterwards, per slot and in fp64:  S_ib = -sum_e A_e S_eb,  S_ii = sum_ee' A_e S_ee' A_e'^T,
+//     (E Q w)_i = -sum_e A_e (E Q w)_e  (ba_schur_fold_kernel).  The per-pixel adjoint action, the four-way
+//     combine of its partial sums through LDS and one barrier per tile disappear from the staging;
+//   * the relative pose is a rotation matrix + translation (12 FMAs per pixel instead of the quaternion
+//     sandwich), Jacobians only (jacobians_pixel);
+//   * fp32 MFMA chains are one 64-pixel tile long and are summed in fp64 registers (tile totals);
+//   * no atomics here: each (slot, pixel range) workgroup writes its fp64 Gram tiles to v.Gpart, the fold kernel
+//     sums the ranges, forms the self blocks and adds ONE atomic per system entry and slot (6x fewer than one per
+//     entry and pixel range).
+// Rows of a slot: 6x + n for its x-th edge (every edge of the slot, window target or not: all of them feed the
+// self row), row R = 6 nedges = w sqrt(Q); padded with zero rows to a multiple of 16.
+// ------------------------------------------------------------------------------------------
+constexpr int S2_MAXT = 6;                 // 6 row tiles of 16 at 16 edges: 21 Gram tiles over 4 waves
+struct Schur2Meta {
+  int e[S2_MAXE];
+  int flag[S2_MAXE];
+  float T[S2_MAXE][12];
+};
+
+// One workgroup = 4 waves that alternate between staging (VALU) and the SYRK (matrix pipe); three workgroups per
+// CU.  A producer / consumer split of the waves (tried: 8 waves, double-buffered LDS) gains nothing on gfx950:
+// fp32 and fp64 MFMAs do not overlap with VALU work of other waves of the same SIMD (tools/micro/
+// mfma_valu_overlap.hip: together = sum of the two alone), so the kernel's time is staging + SYRK whatever the
+// arrangement, and both are minimised instead: the w row is NOT part of the SYRK (one more row tile for a single
+// useful row: 10 instead of 6 Gram tiles at 8 edges): E Q w is accumulated by the staging threads (6 FMAs per
+// edge and pixel) and reduced over the pixels once per workgroup.
+__global__ __launch_bounds__(256, 3) void ba_schur2_kernel(BaView v, const float* __restrict__ poses,
+                                                           const float* __restrict__ disps,
+                                                           const float* __restrict__ intrinsics,
+                                                           const float* __restrict__ weights,
+                                                           const int64_t* __restrict__ jj, int wide) {
+  __shared__ __attribute__((aligned(16))) float EB[6 * S2_MAXE * SF_PITCH];
+  __shared__ Schur2Meta sm;
+  if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
+  const int m = v.order[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HW = v.HW, W = v.W;
+  const int x_beg = v.seg_ptr[m], nedges = v.seg_ptr[m + 1] - x_beg;
+  if (nedges == 0 || nedges > S2_MAXE) return;
+  const int R = 6 * nedges;
+  const int ntr = (R + 15) / 16, ntiles = ntr * (ntr + 1) / 2;
+  const int f = v.kx[m];
+  const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  const int tiles_total = (HW + SF_TP - 1) / SF_TP;
+  const int tpw = (tiles_total + gridDim.y - 1) / gridDim.y;
+  const int tile_beg = blockIdx.y * tpw, tile_end = min(tiles_total, tile_beg + tpw);
+  if (tile_beg >= tile_end) return;
+  const int pixl = tid & (SF_TP - 1), part = tid >> 6;  // four threads per pixel split the edges
+  if (tid < nedges) {
+    const int e = v.seg_edge[x_beg + tid];
+    const int jx = (int)jj[e];
+    const RelMat<float> T = rel_pose_mat<float, true>(poses, f, jx);
+    sm.e[tid] = e;
+    sm.flag[tid] = (jx == f) ? 1 : 0;
+#pragma unroll
+    for (int n = 0; n < 9; n++) sm.T[tid][n] = T.R[n];
+#pragma unroll
+    for (int n = 0; n < 3; n++) sm.T[tid][9 + n] = T.t[n];
+  }
+  // the zero rows behind the last E row never change
+  for (int row = R + part; row < 16 * ntr; row += 4) EB[row * SF_PITCH + pixl] = 0.f;
+  __syncthreads();
+
+  constexpr int NU = S2_MAXE / 4;  // edges per thread
+  float pf_q = 0.f, pf_d = 0.f, pf_wr = 0.f, pf_w[2 * NU];
+  auto prefetch = [&](int tile) {
+    const int k = tile * SF_TP + pixl;
+    const bool ok = (tile < tile_end) && (k < HW);
+    pf_q = ok ? v.Q[(size_t)m * HW + k] : 0.f;
+    pf_d = ok ? disps[(size_t)f * HW + k] : 0.f;
+    pf_wr = ok ? v.w[(size_t)m * HW + k] : 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const int x = part + 4 * u;
+      const bool okx = ok && x < nedges;
+      const float* wg = weights + (size_t)(okx ? sm.e[x] : 0) * 2 * HW;
+      pf_w[2 * u] = okx ? wg[k] : 0.f;
+      pf_w[2 * u + 1] = okx ? wg[HW + k] : 0.f;
+    }
+  };
+
+  double tot[S2_MAXT][4];
+#pragma unroll
+  for (int t = 0; t < S2_MAXT; t++)
+#pragma unroll
+    for (int x = 0; x < 4; x++) tot[t][x] = 0.0;
+  float uacc[NU][6];  // (E Q w) of this thread's edges over its pixels
+#pragma unroll
+  for (int u = 0; u < NU; u++)
+#pragma unroll
+    for (int n = 0; n < 6; n++) uacc[u][n] = 0.f;
+  // LDS offsets of this lane's operand rows: tile wave + 4 t = (ta, tb) of the row-major lower triangle
+  int toff_a[S2_MAXT], toff_b[S2_MAXT];
+#pragma unroll
+  for (int t = 0; t < S2_MAXT; t++) {
+    int ta = 0, rem = min(wave + 4 * t, ntiles - 1);
+    while (rem > ta) {
+      rem -= ta + 1;
+      ta++;
+    }
+    toff_a[t] = (16 * ta + (lane & 15)) * SF_PITCH + 4 * (lane >> 4);
+    toff_b[t] = (16 * rem + (lane & 15)) * SF_PITCH + 4 * (lane >> 4);
+  }
+
+  prefetch(tile_beg);
+  for (int tile = tile_beg; tile < tile_end; tile++) {
+    const int k = tile * SF_TP + pixl;
+    const bool pok = k < HW;
+    const float sq = sqrtf(pf_q), disp = pf_d, wq = pf_wr * sq;
+    float cur_w[2 * NU];
+#pragma unroll
+    for (int u = 0; u < 2 * NU; u++) cur_w[u] = pf_w[u];
+    if (tile > tile_beg) __syncthreads();  // the previous tile has been multiplied
+    // ---- stage B~ = E sqrt(Q) of 64 pixels
+    const float X0 = ((float)(k % W) - K.cx) / K.fx, X1 = ((float)(k / W) - K.cy) / K.fy;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const int x = part + 4 * u;
+      if (x < nedges) {
+        float eij[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (pok && sm.flag[x] == 0) {  // stereo pairs carry no weight in the pose terms (dk:323, :356): zero rows
+          const float* T = sm.T[x];
+          const float px = T[0] * X0 + T[1] * X1 + T[2] + disp * T[9];
+          const float py = T[3] * X0 + T[4] * X1 + T[5] + disp * T[10];
+          const float pz = T[6] * X0 + T[7] * X1 + T[8] + disp * T[11];
+          const bool bad = pz < DROID_MIN_DEPTH;
+          const float d = bad ? 0.f : 1.0f / pz;
+          PixLin L;
+          pix_jacobians(K, px, py, d, disp, T[9], T[10], T[11], L);
+          const float val = bad ? 0.f : 0.001f * sq;   // weights are scaled by 0.001 (dk:305-306), rows by sqrt(Q)
+          const float su = (val * cur_w[2 * u]) * L.Jzu, sv = (val * cur_w[2 * u + 1]) * L.Jzv;
+#pragma unroll
+          for (int n = 0; n < 6; n++) eij[n] = su * L.Ju[n] + sv * L.Jv[n];  // dk:341, :374
+        }
+#pragma unroll
+        for (int n = 0; n < 6; n++) {
+          EB[(6 * x + n) * SF_PITCH + pixl] = eij[n];
+          uacc[u][n] = fmaf(eij[n], wq, uacc[u][n]);   // (E sqrt Q)(w sqrt Q): Ev6x1_kernel dk:1059-1093
+        }
+      }
+    }
+    __syncthreads();
+    prefetch(tile + 1);
+    // ---- SYRK of the tile: wave w owns Gram tiles w, w+4, ...; one fp32 chain per 64-pixel tile, fp64 totals
+#pragma unroll
+    for (int t = 0; t < S2_MAXT; t++) {
+      if (wave + 4 * t < ntiles) {
+        // 16-byte operand reads; K runs in a permuted order (k-step (s,e) of lane group g = pixel 16s+4g+e),
+        // identical for both operands
+        const float* pa = &EB[toff_a[t]];
+        const float* pb = &EB[toff_b[t]];
+        f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < SF_TP; s4 += 16) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(pa + s4);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + s4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) tot[t][x] += (double)c[x];
+      }
+    }
+  }
+  // ---- this pixel range's Gram tiles: [tile][lane][4], 32 bytes per lane; behind them the 6 nedges sums of E Q w
+  double* gp = v.Gpart + ((size_t)v.gt_ptr[m] * gridDim.y + (size_t)blockIdx.y * (ntiles + 1)) * 256;
+#pragma unroll
+  for (int t = 0; t < S2_MAXT; t++) {
+    const int ti = wave + 4 * t;
+    if (ti < ntiles) {
+      double* q = gp + (size_t)ti * 256 + 4 * lane;
+      *reinterpret_cast<double2*>(q) = make_double2(tot[t][0], tot[t][1]);
+      *reinterpret_cast<double2*>(q + 2) = make_double2(tot[t][2], tot[t][3]);
+    }
+  }
+  // E Q w: the per-thread sums go through LDS (the operand tile is free now), row 6x+n, column rotated by the row
+  // so that the 6 nedges summing threads hit different banks; fp64 from here on
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NU; u++) {
+    const int x = part + 4 * u;
+    if (x < nedges) {
+#pragma unroll
+      for (int n = 0; n < 6; n++) EB[(6 * x + n) * SF_TP + ((pixl + 6 * x + n) & (SF_TP - 1))] = uacc[u][n];
+    }
+  }
+  __syncthreads();
+  if (tid < R) {
+    double sacc = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < SF_TP; c++) sacc += (double)EB[tid * SF_TP + ((c + tid) & (SF_TP - 1))];
+    gp[(size_t)ntiles * 256 + tid] = sacc;
+  }
+}
+
+// Per slot: sum the pixel ranges' Gram tiles, derive the self-row blocks (see above) and subtract everything
+// from the dense system: S -= E Q E^T on the lower triangle, rhs -= E Q w.  fp64 throughout.  16 waves: every Gram
+// tile has its own wave (all partial-sum loads of the slot are in flight together), the last wave builds the
+// adjoints meanwhile.
+constexpr int S2_GP = 6 * S2_MAXE + 1;  // pitch of the dense Gram matrix in LDS (97: odd, conflict-free columns)
+constexpr int S2_MAXC = 8;              // pixel ranges summed with all loads in flight (more: a second round)
+__global__ __launch_bounds__(1024) void ba_schur_fold_kernel(BaView v, const float* __restrict__ poses,
+                                                             const int64_t* __restrict__ jj, int nsplit) {
+  __shared__ double G[(6 * S2_MAXE + 1) * S2_GP];  // rows 0..R-1: E Q E^T (both triangles), row R: E Q w
+  __shared__ double As[S2_MAXE][6][6];             // A_e = Adj(T_e)^T
+  __shared__ double Vs[S2_MAXE][6][6];             // V_b = -sum_e A_e S_eb  (= S_ib, the self row against edge b)
+  __shared__ double Sss[6][6], us[6];
+  __shared__ int s_pose[S2_MAXE];                  // window pose of an edge's target, or -1
+  if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
+  const int m = v.order[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x_beg = v.seg_ptr[m], nedges = v.seg_ptr[m + 1] - x_beg;
+  if (nedges == 0 || nedges > S2_MAXE) return;
+  const int R = 6 * nedges;
+  const int ntr = (R + 15) / 16, ntiles = ntr * (ntr + 1) / 2;
+  const int f = v.kx[m];
+  const int tiles_total = (v.HW + SF_TP - 1) / SF_TP;
+  const int tpw = (tiles_total + nsplit - 1) / nsplit;
+  const int nchunk = (tiles_total + tpw - 1) / tpw;  // pixel ranges that hold pixels
+  const int e0 = v.ent_ptr[m];
+  const bool has_self = (v.ent_ptr[m + 1] > e0) && (v.ent_row[e0] < v.M);
+  const int pf = f - v.t0;
+  const double* gp = v.Gpart + (size_t)v.gt_ptr[m] * nsplit * 256;
+  const size_t cstride = (size_t)(ntiles + 1) * 256;
+  if (wave == 15) {
+    if (lane < nedges) {
+      const int e = v.seg_edge[x_beg + lane];
+      const int jx = (int)jj[e];
+      const int pj = jx - v.t0;
+      s_pose[lane] = (pj >= 0 && pj < v.P) ? pj : -1;
+      const RelMat<double> T = rel_pose_mat<double, true>(poses, f, jx);
+#pragma unroll
+      for (int kk = 0; kk < 6; kk++) {
+        double X[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, Y[6];
+        X[kk] = 1.0;
+        adjT_mat(T.R, T.t, X, Y);
+#pragma unroll
+        for (int r = 0; r < 6; r++) As[lane][r][kk] = Y[r];
+      }
+    }
+  } else if (wave == 14) {  // E Q w: 6 nedges sums per pixel range
+    for (int o = lane; o < R; o += 64) {
+      double sacc = 0.0;
+      for (int c = 0; c < nchunk; c++) sacc += gp[(size_t)c * cstride + (size_t)ntiles * 256 + o];
+      G[R * S2_GP + o] = sacc;
+    }
+  } else {
+    // 1. dense Gram matrix: tile ti = (ta, tb), element (lane, x) = row 16 ta + 4 (lane >> 4) + x, column 16 tb + (lane & 15)
+    for (int ti = wave; ti < ntiles; ti += 14) {
+      int ta = 0, tb = ti;
+      while (tb > ta) {
+        tb -= ta + 1;
+        ta++;
+      }
+      double a[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int c0 = 0; c0 < nchunk; c0 += S2_MAXC) {
+        double2 lo[S2_MAXC], hi[S2_MAXC];
+#pragma unroll
+        for (int c = 0; c < S2_MAXC; c++) {
+          const bool ok = c0 + c < nchunk;
+          const double* q = gp + (size_t)(ok ? c0 + c : 0) * cstride + (size_t)ti * 256 + 4 * lane;
+          lo[c] = *reinterpret_cast<const double2*>(q);
+          hi[c] = *reinterpret_cast<const double2*>(q + 2);
+          if (!ok) lo[c] = hi[c] = make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int c = 0; c < S2_MAXC; c++) {
+          a[0] += lo[c].x; a[1] += lo[c].y; a[2] += hi[c].x; a[3] += hi[c].y;
+        }
+      }
+      const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        const int li = 16 * ta + 4 * g + x, lj = 16 * tb + r;
+        if (li >= R || lj >= R) continue;
+        G[li * S2_GP + lj] = a[x];
+        if (ta != tb) G[lj * S2_GP + li] = a[x];
+      }
+    }
+  }
+  __syncthreads();
+  // 2. self-row blocks
+  if (has_self) {
+    for (int o = tid; o < nedges * 36; o += 1024) {
+      const int b = o / 36, r = (o / 6) % 6, c = o % 6;
+      double sacc = 0.0;
+      for (int e = 0; e < nedges; e++)
+#pragma unroll
+        for (int kk = 0; kk < 6; kk++) sacc -= As[e][r][kk] * G[(6 * e + kk) * S2_GP + 6 * b + c];
+      Vs[b][r][c] = sacc;
+    }
+    if (tid >= 960 && tid < 966) {
+      const int r = tid - 960;
+      double sacc = 0.0;
+      for (int e = 0; e < nedges; e++)
+#pragma unroll
+        for (int kk = 0; kk < 6; kk++) sacc -= As[e][r][kk] * G[R * S2_GP + 6 * e + kk];
+      us[r] = sacc;
+    }
+    __syncthreads();
+    if (tid < 36) {
+      const int r = tid / 6, c = tid % 6;
+      double sacc = 0.0;
+      for (int b = 0; b < nedges; b++)
+#pragma unroll
+        for (int kk = 0; kk < 6; kk++) sacc -= Vs[b][r][kk] * As[b][c][kk];
+      Sss[r][c] = sacc;
+    }
+    __syncthreads();
+  }
+  // 3. scatter: entries = window edges (+ the self entry, index nedges)
+  const int nrow = R + (has_self ? 6 : 0);
+  double* S = v.sys;
+  const int n = v.n, ld = v.ld;
+  for (int o = tid; o < nrow * nrow; o += 1024) {
+    const int ia = o / nrow, ib = o % nrow;
+    const int a = ia / 6, r = ia % 6, b = ib / 6, c = ib % 6;
+    const int pa = (a == nedges) ? pf : s_pose[a], pb = (b == nedges) ? pf : s_pose[b];
+    if (pa < 0 || pb < 0) continue;
+    const int gi = 6 * pa + r, gj = 6 * pb + c;
+    if (gi < gj) continue;
+    double val;
+    if (a < nedges && b < nedges) val = G[ia * S2_GP + ib];
+    else if (a == nedges && b == nedges) val = Sss[r][c];
+    else if (a == nedges) val = Vs[b][r][c];
+    else val = Vs[a][c][r];
+    atomicAdd(&S[(size_t)gi * ld + gj], -val);
+  }
+  for (int o = tid; o < nrow; o += 1024) {
+    const int a = o / 6, r = o % 6;
+    const int pa = (a == nedges) ? pf : s_pose[a];
+    if (pa < 0) continue;
+    const double val = (a == nedges) ? us[r] : G[R * S2_GP + o];
+    atomicAdd(&S[(size_t)n * ld + 6 * pa + r], -val);
+  }
+}
+
 // (ta, tb), tb <= ta, of index ti in the row-major enumeration of a lower triangle
 __device__ __forceinline__ void tri_coords(int ti, int& ta, int& tb) {
   int a = (int)((sqrtf(8.0f * (float)ti + 1.0f) - 1.0f) * 0.5f);
@@ -1283,25 +1655,28 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
                         int stage, hipStream_t s) {
   const bool depth = !motion_only && v.M > 0;
   switch (stage) {
-    case 0:
-      (void)hipMemsetAsync(v.sys, 0, sizeof(double) * (size_t)(v.n + 1) * v.ld, s);
+    case 0: {
+      constexpr int ZB = 192;  // workgroups of the linearisation launch that clear the system instead
       if (depth) {
-        const dim3 g(v.M, v.nch, v.zsplit), b(LIN_THREADS);
+        const dim3 g(v.M + ZB, v.nch, v.zsplit), b(LIN_THREADS);
         if (v.wide && v.zsplit > 1)
-          hipLaunchKernelGGL((ba_lin_kernel<true, true, true>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj);
+          hipLaunchKernelGGL((ba_lin_kernel<true, true, true>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj, v.M);
         else if (v.wide)
-          hipLaunchKernelGGL((ba_lin_kernel<true, true, false>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj);
+          hipLaunchKernelGGL((ba_lin_kernel<true, true, false>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj, v.M);
         else if (v.zsplit > 1)
-          hipLaunchKernelGGL((ba_lin_kernel<true, false, true>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj);
+          hipLaunchKernelGGL((ba_lin_kernel<true, false, true>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj, v.M);
         else
-          hipLaunchKernelGGL((ba_lin_kernel<true, false, false>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj);
+          hipLaunchKernelGGL((ba_lin_kernel<true, false, false>), g, b, 0, s, v, poses, disps, intr, sens, targets, weights, eta, ii, jj, v.M);
         if (v.zsplit > 1)
           hipLaunchKernelGGL(ba_lin_finish_kernel, dim3(v.M, (v.HW + 255) / 256), dim3(256), 0, s, v, disps, sens, eta);
       } else if (v.E > 0) {
-        hipLaunchKernelGGL((ba_lin_kernel<false, false, false>), dim3(v.E, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
-                           disps, intr, sens, targets, weights, eta, ii, jj);
+        hipLaunchKernelGGL((ba_lin_kernel<false, false, false>), dim3(v.E + ZB, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
+                           disps, intr, sens, targets, weights, eta, ii, jj, v.E);
+      } else {
+        (void)hipMemsetAsync(v.sys, 0, sizeof(double) * (size_t)(v.n + 1) * v.ld, s);
       }
       break;
+    }
     case 1:
       if (v.E > 0)
         hipLaunchKernelGGL(ba_assemble_kernel, dim3(v.E + (solver_preset_words(v) + 1023) / 1024 + solver_preset_tiles(v)), dim3(64), 0, s, v, poses, ii, jj);
@@ -1315,8 +1690,9 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
         // dense graphs (mean out-degree >= 12: global BA of a well connected graph, edge-sharded
         // ranks) send their slots of 17..85 entries to the wide kernels
         const int wide = v.wide;
-        hipLaunchKernelGGL(ba_schur_fused_kernel<false>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
-                           intr, weights, ii, jj, wide);
+        // sparse slots (<= S2_MAXE edges): Gram tiles per pixel range, then the per-slot fold
+        hipLaunchKernelGGL(ba_schur2_kernel, dim3(v.M, v.s2_split), dim3(256), 0, s, v, poses, disps, intr, weights, jj, wide);
+        hipLaunchKernelGGL(ba_schur_fold_kernel, dim3(v.M), dim3(1024), 0, s, v, poses, jj, v.s2_split);
         hipLaunchKernelGGL(ba_schur_fused_kernel<true>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
                            intr, weights, ii, jj, wide);
         if (wide) {  // dense slots: SYRK straight from the E rows the linearisation wrote (v.Ebuf)
