@@ -170,15 +170,20 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(d) to fp64 accuracy: v_rsq_f64 seed + Newton (the pivot wave is instruction-count bound,
-// so the seed comes from the fp64 unit directly instead of cvt -> v_rsq_f32 -> cvt).
+// 1/sqrt(d) to fp64 accuracy: v_rsq_f64 seed (24 bits, tools/micro/rsq_acc.hip) + ONE third-order (Halley) step
+//   e = 1 - d y^2,  y <- y + y e (1/2 + 3/8 e)        (next term 5/16 e^3 ~ 4e-23)
+// = 5 instructions instead of the 8 of two Newton steps (-2.5 us per 1530-pivot factorisation, same residuals).
 __device__ __forceinline__ double rsqrt_nr(double d) {
   double y = __builtin_amdgcn_rsq(d);
+#ifdef CHOL_TWO_NEWTON
   double e = fma(-d * y, y, 1.0);
   y = fma(0.5 * y, e, y);
-#ifndef CHOL_ONE_NEWTON
   e = fma(-d * y, y, 1.0);
   y = fma(0.5 * y, e, y);
+#else
+  const double e = fma(-d * y, y, 1.0);
+  const double p = fma(0.375, e, 0.5);
+  y = fma(y * e, p, y);
 #endif
   return y;
 }

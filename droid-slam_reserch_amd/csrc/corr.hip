@@ -13,6 +13,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/droid_backends_hip.h"
 
@@ -1179,11 +1180,175 @@ __global__ __launch_bounds__(256) void altcorr_backward_kernel(
   }
 }
 
+// ---- altcorr_backward, tiled ------------------------------------------------------------------------------------
+// The per-tap kernel above issues one global float atomic per (query, tap, channel): 805 M atomics for 32 edges at
+// 48x64 x 128 channels, 2.9 ms at the chip's ~0.3 T atomics/s.  Here one workgroup owns an 8x8 tile of queries of
+// one (edge, coordinate set).  The windows of neighbouring queries overlap almost completely, so the fmap2 gradient
+// is formed per POSITION of the tile's bounding box as a gather over the queries whose window covers it:
+//   fmap2_grad[pos] += sum_{q in tile, pos in window(q)} g(q, tap(q, pos)) fmap1[q]
+// with the list of (query, tap) pairs of every position built once per workgroup in LDS (11 of the 64 queries on
+// average at r = 3, all 64 in the middle of the box) and reused for all channels; a position leaves the workgroup as ONE global atomic per channel
+// (~360 positions for 64 x 64 taps: 11x fewer atomics).  Accumulating per position with LDS atomics instead
+// (ds_add_f32 from query-owning threads) was measured first and is slower than the global atomics it replaces
+// (4.1 ms: LDS float atomics retire a few lanes per cycle).  The query's own gradient (fmap1_grad) is a register sum
+// over its taps.  The 64 bilinear-combined tap gradients g (ak:228-246) of every query are formed once, in LDS.
+constexpr int ABT = 8;              // tile is ABT x ABT queries
+constexpr int AB_CH = 16;           // channels per pass (4 per thread)
+constexpr int AB_MAXPOS = 448;      // largest box handled with hit lists (21 x 21 at r = 4); bigger boxes take per-tap atomics
+constexpr int AB_HMAX = ABT * ABT;  // a position in the middle of the box is covered by every query of the tile
+
+template <int R>
+__global__ __launch_bounds__(256) void altcorr_backward_tiled(
+    const float* __restrict__ fmap1, const float* __restrict__ fmap2, const float* __restrict__ coords,
+    const float* __restrict__ corr_grad, float* __restrict__ fmap1_grad, float* __restrict__ fmap2_grad, int N,
+    int H1, int W1, int H2, int W2, int C) {
+  constexpr int RD = 2 * R + 1, NT = RD + 1, NTAP = NT * NT;
+  __shared__ unsigned short hits[AB_MAXPOS][AB_HMAX + 2];   // +2: rows of 33 dwords, conflict-free across positions
+  __shared__ unsigned char hcnt[AB_MAXPOS];
+  __shared__ float gq[ABT * ABT][NTAP + 1];
+  __shared__ __attribute__((aligned(16))) float f1s[ABT * ABT][AB_CH + 4];  // pitch 20: 16-byte reads of 8 queries cover all banks
+  __shared__ int qorg[ABT * ABT][2];
+  __shared__ int bbox[4];
+  const int tid = threadIdx.x;
+  const int qq = tid >> 2, cq = tid & 3;
+  const int tiles_x = (W1 + ABT - 1) / ABT;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int n = blockIdx.y, b = blockIdx.z;
+  const int qx = tx * ABT + (qq & (ABT - 1)), qy = ty * ABT + (qq / ABT);
+  const bool qok = qx < W1 && qy < H1;
+  const int H1W1 = H1 * W1;
+  const int pix = qok ? qy * W1 + qx : 0;
+  const float* cp = coords + (((size_t)b * N + n) * H1W1 + pix) * 2;
+  const Bilin bl = bilin_setup(cp[0], cp[1], R);
+  if (tid < 4) bbox[tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;
+  __syncthreads();
+  const bool hit = qok && bl.x1 + NT > 0 && bl.x1 < W2 && bl.y1 + NT > 0 && bl.y1 < H2;
+  if (cq == 0) {
+    qorg[qq][0] = hit ? bl.x1 : -0x3fffffff;   // queries outside the map / the image never match a position
+    qorg[qq][1] = hit ? bl.y1 : -0x3fffffff;
+    if (hit) {
+      atomicMin(&bbox[0], max(bl.x1, 0));
+      atomicMin(&bbox[1], max(bl.y1, 0));
+      atomicMax(&bbox[2], min(bl.x1 + NT, W2));
+      atomicMax(&bbox[3], min(bl.y1 + NT, H2));
+    }
+  }
+  // the tap gradients of this query: g(iy, ix) = the four bilinear shares of corr_grad that tap (iy, ix) feeds
+  {
+    const float* cg = corr_grad + (((size_t)b * N + n) * RD * RD) * H1W1 + pix;
+    const float wnw = bl.dy * bl.dx, wne = bl.dy * (1.f - bl.dx), wsw = (1.f - bl.dy) * bl.dx, wse = (1.f - bl.dy) * (1.f - bl.dx);
+    for (int t = cq; t < NTAP; t += 4) {
+      const int iy = t / NT, ix = t % NT;
+      float g = 0.f;  // ak:228-246, same order of the four terms
+      if (qok) {
+        if (iy > 0 && ix > 0) g += cg[(size_t)((iy - 1) + RD * (ix - 1)) * H1W1] * wnw;
+        if (iy > 0 && ix < RD) g += cg[(size_t)((iy - 1) + RD * ix) * H1W1] * wne;
+        if (iy < RD && ix > 0) g += cg[(size_t)(iy + RD * (ix - 1)) * H1W1] * wsw;
+        if (iy < RD && ix < RD) g += cg[(size_t)(iy + RD * ix) * H1W1] * wse;
+      }
+      gq[qq][t] = g;
+    }
+  }
+  __syncthreads();
+  const int bx0 = bbox[0], by0 = bbox[1];
+  const int BW = max(bbox[2] - bx0, 0), BH = max(bbox[3] - by0, 0);
+  const int npos = BW * BH;
+  if (npos == 0) return;  // no window of the tile touches the map: all gradients are zero (outputs are pre-zeroed)
+  const float* f1 = fmap1 + ((size_t)b * H1W1 + pix) * C;
+  float* g1 = fmap1_grad + ((size_t)b * H1W1 + pix) * C;
+  const float* f2b = fmap2 + (size_t)b * H2 * W2 * C;
+  float* g2b = fmap2_grad + (size_t)b * H2 * W2 * C;
+  // hit lists: the (query, tap) pairs of every box position, in query order
+  if (npos <= AB_MAXPOS) {
+    for (int pp = tid; pp < npos; pp += 256) {
+      const int py = pp / BW, px = pp - py * BW;
+      const int gx = bx0 + px, gy = by0 + py;
+      int cnt = 0;
+      for (int q = 0; q < ABT * ABT; q++) {
+        const unsigned dx = (unsigned)(gx - qorg[q][0]), dy = (unsigned)(gy - qorg[q][1]);
+        if (dx < (unsigned)NT && dy < (unsigned)NT) {
+          hits[pp][cnt] = (unsigned short)((q << 8) | (dy * NT + dx));
+          cnt++;
+        }
+      }
+      hcnt[pp] = (unsigned char)cnt;
+    }
+  }
+  __syncthreads();
+  if (npos > AB_MAXPOS) {
+    // incoherent tile: per-tap global atomics like altcorr_backward_kernel (each thread takes every 4th channel)
+    if (!qok) return;
+    for (int iy = 0; iy < NT; iy++)
+      for (int ix = 0; ix < NT; ix++) {
+        const int h2 = bl.y1 + iy, w2 = bl.x1 + ix;
+        if (h2 < 0 || h2 >= H2 || w2 < 0 || w2 >= W2) continue;
+        const float g = gq[qq][iy * NT + ix];
+        const size_t po = ((size_t)h2 * W2 + w2) * C;
+        for (int c = cq; c < C; c += 4) {
+          atomicAdd(&g1[c], g * f2b[po + c]);
+          atomicAdd(&g2b[po + c], g * f1[c]);
+        }
+      }
+    return;
+  }
+  for (int c0 = 0; c0 < C; c0 += AB_CH) {
+    const int cb = c0 + 4 * cq;  // this thread's 4 channels (C % 16 == 0 on this path)
+    const f4 u0 = qok ? *reinterpret_cast<const f4*>(f1 + cb) : f4{0.f, 0.f, 0.f, 0.f};
+    if (c0 > 0) __syncthreads();  // the previous pass has read f1s
+    *reinterpret_cast<f4*>(&f1s[qq][4 * cq]) = u0;
+    __syncthreads();
+    // fmap2 gradient: one (position, 4 channels) unit at a time, gathered over its hit list (one channel per lane
+    // with 64-byte contiguous atomics was measured slower: 1.28 vs 0.92 ms -- the gather, not the atomics, is the cost)
+    for (int u = tid; u < 4 * npos; u += 256) {
+      const int pp = u >> 2, cg4 = u & 3;
+      const int cnt = hcnt[pp];
+      if (cnt == 0) continue;
+      f4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int h = 0; h < cnt; h++) {
+        const unsigned hv = hits[pp][h];
+        const float g = gq[hv >> 8][hv & 255];
+        a += g * *reinterpret_cast<const f4*>(&f1s[hv >> 8][4 * cg4]);
+      }
+      const int py = pp / BW, px = pp - py * BW;
+      float* dst = g2b + ((size_t)(by0 + py) * W2 + (bx0 + px)) * C + c0 + 4 * cg4;
+#pragma unroll
+      for (int k = 0; k < 4; k++) atomicAdd(&dst[k], a[k]);
+    }
+    // fmap1 gradient of this thread's query and channels: register sum over the window
+    if (qok) {
+      f4 a0 = {0.f, 0.f, 0.f, 0.f};
+      for (int iy = 0; iy < NT; iy++) {
+        const int h2 = bl.y1 + iy;
+        if (h2 < 0 || h2 >= H2) continue;
+#pragma unroll 4
+        for (int ix = 0; ix < NT; ix++) {
+          const int w2 = bl.x1 + ix;
+          if (w2 < 0 || w2 >= W2) continue;
+          a0 += gq[qq][iy * NT + ix] * *reinterpret_cast<const f4*>(f2b + ((size_t)h2 * W2 + w2) * C + cb);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) atomicAdd(&g1[cb + k], a0[k]);  // other coordinate sets (n) add to the same rows
+    }
+  }
+}
+
 int launch_altcorr_backward(const float* f1, const float* f2, const float* coords,
                             const float* corr_grad, float* f1g, float* f2g, int B, int N, int H1,
                             int W1, int H2, int W2, int C, int r, hipStream_t s) {
   if (B > 65535 || N > 65535) return DROID_E_ARG;
   const int HW = H1 * W1;
+  static const bool per_tap = (getenv("DROID_ALTCORR_BWD_PER_TAP") != nullptr);  // diagnostics: the old kernel
+  if (!per_tap && (C % AB_CH) == 0 && (r == 3 || r == 4)) {
+    const int tiles = ((W1 + ABT - 1) / ABT) * ((H1 + ABT - 1) / ABT);
+    if (r == 3)
+      hipLaunchKernelGGL((altcorr_backward_tiled<3>), dim3(tiles, N, B), dim3(256), 0, s, f1, f2, coords, corr_grad, f1g,
+                         f2g, N, H1, W1, H2, W2, C);
+    else
+      hipLaunchKernelGGL((altcorr_backward_tiled<4>), dim3(tiles, N, B), dim3(256), 0, s, f1, f2, coords, corr_grad, f1g,
+                         f2g, N, H1, W1, H2, W2, C);
+    return 0;
+  }
   hipLaunchKernelGGL(altcorr_backward_kernel, dim3((HW * 16 + 255) / 256, N, B), dim3(256), 0, s, f1,
                      f2, coords, corr_grad, f1g, f2g, N, HW, H2, W2, C, r);
   return 0;
