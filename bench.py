@@ -234,7 +234,11 @@ def bench_corr(args, rank, world, dev, prob):
     gi, gj = gi.reshape(-1).contiguous(), gj.reshape(-1).contiguous()
     ms_fd = timeit(lambda: db.frame_distance(pz, dz, kz, gi, gj, 0.3), 3)
     out["frame_distance_all_pairs"] = dict(pairs=int(gi.numel()), ms=ms_fd, gpix_per_s=gi.numel() * H * W / ms_fd / 1e6,
-                                           kernel="frame_distance_kernel, 65536 pairs x 3072 pixels")
+                                           kernel="frame_distance_kernel, 65536 pairs x 3072 pixels (one direction)")
+    ms_fm = timeit(lambda: db.frame_distance_matrix(pz, dz, kz, Nk, 0.3), 3)
+    out["frame_distance_matrix"] = dict(pairs=int(Nk * Nk), ms=ms_fm, gpix_per_s=Nk * Nk * H * W / ms_fm / 1e6,
+                                        kernel="frame_distance_matrix_kernel: DepthVideo.distance(ii=None), bidirectional, "
+                                               "one launch, no index tensors (the reference makes two frame_distance calls)")
     # the two training-only operators (modules/corr.py:15-20, :82-88), level 0, a smaller batch: scatter-adds
     Bb = min(B, 32)
     vb, cb = pyramid[0][:Bb].contiguous(), cl[0][:Bb].contiguous()

@@ -30,6 +30,8 @@ int launch_altcorr_backward(const float* f1, const float* f2, const float* coord
 void launch_frame_distance(const float* poses, const float* disps, const float* intr,
                            const int64_t* ii, const int64_t* jj, int E, int nbuf, int H, int W,
                            float beta, float* dist, hipStream_t s);
+void launch_frame_distance_matrix(const float* poses, const float* disps, const float* intr, int n, int H, int W,
+                                  float beta, float* dist, hipStream_t s);
 void launch_projmap(const float* poses, const float* disps, const float* intr, const int64_t* ii,
                     const int64_t* jj, int E, int nbuf, int H, int W, float* coords, float* valid,
                     hipStream_t s);
@@ -348,6 +350,15 @@ int droid_frame_distance(const float* poses, const float* disps, const float* in
   if (!poses || !disps || !intrinsics || !ii || !jj || !dist) return fail(DROID_E_ARG, "frame_distance: null %s", "pointer");
   launch_frame_distance(poses, disps, intrinsics, ii, jj, E, nbuf, H, W, beta, dist, (hipStream_t)stream);
   return check_hip("frame_distance");
+}
+
+int droid_frame_distance_matrix(const float* poses, const float* disps, const float* intrinsics, int n, int nbuf,
+                                int H, int W, float beta, float* dist, void* stream) {
+  if (n < 0 || nbuf <= 0 || n > nbuf || H <= 0 || W <= 0) return fail(DROID_E_ARG, "frame_distance_matrix: bad %s", "sizes");
+  if (n == 0) return DROID_OK;
+  if (!poses || !disps || !intrinsics || !dist) return fail(DROID_E_ARG, "frame_distance_matrix: null %s", "pointer");
+  launch_frame_distance_matrix(poses, disps, intrinsics, n, H, W, beta, dist, (hipStream_t)stream);
+  return check_hip("frame_distance_matrix");
 }
 
 int droid_projmap(const float* poses, const float* disps, const float* intrinsics,

@@ -73,6 +73,87 @@ __global__ __launch_bounds__(256) void frame_distance_kernel(
   }
 }
 
+// All ordered pairs (i, j), i, j < n, in ONE launch (`DepthVideo.distance()` with ii = None,
+// depth_video.py:160-190; the candidate matrix of add_proximity_factors, factor_graph.py:318-326): a workgroup owns
+// a source frame i and FD_JB target frames: the depth map of frame i (12 KB at 48 x 64) is fetched from memory once
+// per (i, target block) and then served by L1 / L2 instead of once per pair, the relative poses of the block are
+// formed once, and no index tensors exist.  Same arithmetic per pair as frame_distance_kernel (dk:518-657).
+// dist[i * n + j] = distance i -> j.
+constexpr int FD_JB = 32;    // targets per workgroup
+__global__ __launch_bounds__(256) void frame_distance_matrix_kernel(
+    const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intrinsics,
+    float* __restrict__ dist, int n, int H, int W, float beta) {
+  __shared__ float Ts[FD_JB][8];
+  __shared__ float red[FD_JB][2][4];
+  __shared__ float tot[4];
+  const int i = blockIdx.x, j0 = blockIdx.y * FD_JB, tid = threadIdx.x;
+  const int nj = min(FD_JB, n - j0);
+  const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  const int HW = H * W;
+  if (tid < nj) {
+    const Rel T = rel_pose_plain(poses, i, j0 + tid);
+#pragma unroll
+    for (int c = 0; c < 3; c++) Ts[tid][c] = T.t[c];
+#pragma unroll
+    for (int c = 0; c < 4; c++) Ts[tid][3 + c] = T.q[c];
+  }
+  {  // `total` of dk:618-655 (beta + (1 - beta) per pixel, accumulated like the per-pair kernel): the same for all targets
+    float total = 0.f;
+    for (int k = tid; k < HW; k += 256) {
+      total += beta;
+      total += (1.f - beta);
+    }
+    total = wave_sum(total);
+    if ((tid & 63) == 0) tot[tid >> 6] = total;
+  }
+  __syncthreads();
+  for (int jj = 0; jj < nj; jj++) {
+    Rel T;
+#pragma unroll
+    for (int c = 0; c < 3; c++) T.t[c] = Ts[jj][c];
+#pragma unroll
+    for (int c = 0; c < 4; c++) T.q[c] = Ts[jj][3 + c];
+    float accum = 0.f, valid = 0.f;
+    for (int k = tid; k < HW; k += 256) {   // the depth map stays in L1 / L2 across the targets of the block
+      const float u = (float)(k % W), v = (float)(k / W);
+      const float d0 = disps[(size_t)i * HW + k];
+      float Xj[4];
+      transform_pixel(K, T, u, v, d0, Xj);
+      float du = K.fx * (Xj[0] / Xj[2]) + K.cx - u;
+      float dv = K.fy * (Xj[1] / Xj[2]) + K.cy - v;
+      float d = sqrtf(du * du + dv * dv);
+      if (Xj[2] > DROID_MIN_DEPTH) {
+        accum += beta * d;
+        valid += beta;
+      }
+      const float X0 = (u - K.cx) / K.fx, X1 = (v - K.cy) / K.fy;
+      Xj[0] = X0 + d0 * T.t[0];
+      Xj[1] = X1 + d0 * T.t[1];
+      Xj[2] = 1.f + d0 * T.t[2];
+      du = K.fx * (Xj[0] / Xj[2]) + K.cx - u;
+      dv = K.fy * (Xj[1] / Xj[2]) + K.cy - v;
+      d = sqrtf(du * du + dv * dv);
+      if (Xj[2] > DROID_MIN_DEPTH) {
+        accum += (1.f - beta) * d;
+        valid += (1.f - beta);
+      }
+    }
+    accum = wave_sum(accum);
+    valid = wave_sum(valid);
+    if ((tid & 63) == 0) {
+      red[jj][0][tid >> 6] = accum;
+      red[jj][1][tid >> 6] = valid;
+    }
+  }
+  __syncthreads();
+  if (tid < nj) {
+    const float a = red[tid][0][0] + red[tid][0][1] + red[tid][0][2] + red[tid][0][3];
+    const float vl = red[tid][1][0] + red[tid][1][1] + red[tid][1][2] + red[tid][1][3];
+    const float tt = tot[0] + tot[1] + tot[2] + tot[3];
+    dist[(size_t)i * n + j0 + tid] = (vl / (tt + 1e-8f) < 0.75f) ? 1000.0f : a / vl;  // dk:655
+  }
+}
+
 // projmap_kernel dk:427-516
 __global__ __launch_bounds__(256) void projmap_kernel(
     const float* __restrict__ poses, const float* __restrict__ disps,
@@ -227,6 +308,12 @@ void launch_frame_distance(const float* poses, const float* disps, const float* 
                            float beta, float* dist, hipStream_t s) {
   hipLaunchKernelGGL(frame_distance_kernel, dim3(E), dim3(256), 0, s, poses, disps, intr, ii, jj,
                      dist, nbuf, H, W, beta);
+}
+
+void launch_frame_distance_matrix(const float* poses, const float* disps, const float* intr, int n, int H, int W,
+                                  float beta, float* dist, hipStream_t s) {
+  hipLaunchKernelGGL(frame_distance_matrix_kernel, dim3(n, (n + FD_JB - 1) / FD_JB), dim3(256), 0, s, poses, disps,
+                     intr, dist, n, H, W, beta);
 }
 
 void launch_projmap(const float* poses, const float* disps, const float* intr, const int64_t* ii,

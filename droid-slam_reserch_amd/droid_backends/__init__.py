@@ -19,7 +19,7 @@ from ._lib import DroidBackendError  # noqa: F401
 
 __all__ = ["ba", "frame_distance", "projmap", "depth_filter", "iproj", "altcorr_forward",
            "altcorr_backward", "corr_index_forward", "corr_index_backward",
-           "altcorr_pyramid_forward", "reproject", "motion_features"]  # the last three are additions
+           "altcorr_pyramid_forward", "reproject", "motion_features", "frame_distance_matrix"]  # the last four are additions
 
 _DT = {torch.float16: _lib.DROID_F16, torch.float32: _lib.DROID_F32, torch.float64: _lib.DROID_F64}
 _workspaces = {}   # (device index, stream handle) -> _Workspace
@@ -191,6 +191,24 @@ def frame_distance(poses, disps, intrinsics, ii, jj, beta):
                                         ii.data_ptr(), jj.data_ptr(), E, nbuf, H, W, float(beta),
                                         dist.data_ptr(), _stream()), "frame_distance")
     return dist
+
+
+def frame_distance_matrix(poses, disps, intrinsics, n, beta, bidirectional=True):
+    """`DepthVideo.distance(ii=None)` (droid_slam/depth_video.py:160-190) in one launch: the [n, n] matrix of frame
+    distances between the first n frames, d[i, j] = .5 * (frame_distance(i -> j) + frame_distance(j -> i)) when
+    `bidirectional` (the reference's default), else frame_distance(i -> j).  No meshgrid index tensors, one kernel
+    instead of two, each depth map fetched once per 32 targets.  An addition."""
+    lib = _lib.load()
+    for x, nm in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics")):
+        _check_f32(x, nm)
+    nbuf, H, W = disps.shape
+    nbuf = min(int(nbuf), int(poses.shape[0]))
+    n = int(n)
+    d = torch.empty((n, n), dtype=torch.float32, device=poses.device)
+    _lib.check(lib.droid_frame_distance_matrix(poses.data_ptr(), disps.data_ptr(), intrinsics.data_ptr(), n, nbuf,
+                                               int(H), int(W), float(beta), d.data_ptr(), _stream()),
+               "frame_distance_matrix")
+    return .5 * (d + d.t()) if bidirectional else d
 
 
 def projmap(poses, disps, intrinsics, ii, jj):

@@ -20,7 +20,7 @@ SYMBOLS = [
     "droid_ba_workspace_bytes", "droid_ba", "droid_ba_prepare", "droid_ba_build",
     "droid_ba_solve_update", "droid_ba_profile_iteration", "droid_ba_system", "droid_ba_status",
     "droid_ba_attach_status_mirror", "droid_chol_solve", "droid_chol_scratch_doubles", "droid_reproject_motion",
-    "droid_frame_distance", "droid_projmap", "droid_iproj", "droid_depth_filter",
+    "droid_frame_distance", "droid_frame_distance_matrix", "droid_projmap", "droid_iproj", "droid_depth_filter",
 ]
 
 DROID_F16, DROID_F32, DROID_F64 = 0, 1, 2
@@ -70,6 +70,7 @@ def load() -> ctypes.CDLL:
     lib.droid_chol_scratch_doubles.argtypes = [c_int]
     lib.droid_chol_scratch_doubles.restype = ctypes.c_size_t
     lib.droid_frame_distance.argtypes = [vp] * 5 + [c_int] * 4 + [c_float, vp, vp]
+    lib.droid_frame_distance_matrix.argtypes = [vp] * 3 + [c_int] * 4 + [c_float, vp, vp]
     lib.droid_projmap.argtypes = [vp] * 5 + [c_int] * 4 + [vp, vp, vp]
     lib.droid_iproj.argtypes = [vp] * 3 + [c_int] * 3 + [vp, vp]
     lib.droid_depth_filter.argtypes = [vp] * 5 + [c_int] * 4 + [vp, vp]

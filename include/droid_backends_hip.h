@@ -178,6 +178,15 @@ int droid_frame_distance(const float *poses, const float *disps, const float *in
                          const int64_t *ii, const int64_t *jj, int E, int nbuf, int H, int W,
                          float beta, float *dist, void *stream);
 
+/* All ordered pairs of the first n frames in one launch: dist [n,n] f32, dist[i*n + j] = the value
+ * droid_frame_distance gives for the edge i -> j.  This is `DepthVideo.distance()` with ii = None
+ * (droid_slam/depth_video.py:160-169: meshgrid indices) and the candidate matrix of add_proximity_factors
+ * (factor_graph.py:318-326) without index tensors, and with each depth map fetched once per block of 32
+ * targets instead of once per pair (SURVEY.md section 8f row 1 "batched all-pairs variant").  Not one of the
+ * reference's nine operators.  poses / disps hold at least nbuf >= n frames. */
+int droid_frame_distance_matrix(const float *poses, const float *disps, const float *intrinsics, int n,
+                                int nbuf, int H, int W, float beta, float *dist, void *stream);
+
 /* projmap (droid.cpp:139-154 -> droid_kernels.cu:427-516, :1463-1488):
  * coords [E,H,W,3] f32 (channel 2 zero), valid [E,H,W,1] f32 */
 int droid_projmap(const float *poses, const float *disps, const float *intrinsics,

@@ -214,6 +214,17 @@ def test_distance_matrix_and_candidate_pairs(backends, oracle):
     fin = np.isfinite(ref) & (ref < 1e3)
     assert np.array_equal(np.isfinite(got) & (got < 1e3), fin)
     assert np.abs(got[fin] - ref[fin]).max() < 1e-3 * max(1.0, np.abs(ref[fin]).max())
+    # the one-launch all-pairs variant (no index tensors) against the meshgrid call sequence above and the oracle
+    dm = backends.frame_distance_matrix(video.poses, video.disps, video.intrinsics[0], n, 0.3)
+    assert tuple(dm.shape) == (n, n)
+    gm = dm.cpu().numpy()
+    assert np.array_equal(np.isfinite(gm) & (gm < 1e3), fin)
+    assert np.abs(gm[fin] - ref[fin]).max() < 1e-3 * max(1.0, np.abs(ref[fin]).max())
+    assert np.abs(gm[fin] - got[fin]).max() < 1e-5 * max(1.0, np.abs(got[fin]).max())
+    d1 = backends.frame_distance_matrix(video.poses, video.disps, video.intrinsics[0], n, 0.3, bidirectional=False)
+    r1m = r1.reshape(n, n)
+    f1m = np.isfinite(r1m) & (r1m < 1e3)
+    assert np.abs(d1.cpu().numpy()[f1m] - r1m[f1m]).max() < 1e-3 * max(1.0, np.abs(r1m[f1m]).max())
     ix = torch.arange(0, n)
     jx = torch.arange(2, n)
     ii, jj = torch.meshgrid(ix, jx, indexing="ij")
