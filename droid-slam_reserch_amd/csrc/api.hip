@@ -188,20 +188,59 @@ int droid_ba_prepare(const int64_t* ii, const int64_t* jj, int E, int nbuf, int 
   return check_hip("ba_prepare");
 }
 
-int droid_ba_build(const float* poses, const float* disps, const float* intrinsics,
-                   const float* disps_sens, const float* targets, const float* weights,
-                   const float* eta, const int64_t* ii, const int64_t* jj, int E, int nbuf, int H,
-                   int W, int M, int t0, int t1, int motion_only, void* workspace,
-                   size_t workspace_bytes, void* stream) {
+} // extern "C"
+static int ba_build_impl(const float* poses, const float* disps, const float* intrinsics,
+                         const float* disps_sens, const float* targets, const float* weights,
+                         const float* eta, const int64_t* ii, const int64_t* jj, int E, int nbuf, int H,
+                         int W, int M, int t0, int t1, int motion_only, void* workspace,
+                         size_t workspace_bytes, void* stream, int packed) {
   BaView v;
   int rc = ba_view(v, workspace, workspace_bytes, E, nbuf, H, W, t0, t1, M, motion_only);
   if (rc) return rc;
+  v.packed = packed;
   if (!poses || !disps || !intrinsics) return fail(DROID_E_ARG, "ba: null %s", "state pointer");
   if (E > 0 && (!targets || !weights || !ii || !jj)) return fail(DROID_E_ARG, "ba: null %s", "edge data");
   if (!motion_only && (!eta || !disps_sens)) return fail(DROID_E_ARG, "ba: null %s", "eta/disps_sens");
   launch_build(v, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
                motion_only != 0, (hipStream_t)stream);
   return check_hip("ba_build");
+}
+extern "C" {
+
+int droid_ba_build(const float* poses, const float* disps, const float* intrinsics,
+                   const float* disps_sens, const float* targets, const float* weights,
+                   const float* eta, const int64_t* ii, const int64_t* jj, int E, int nbuf, int H,
+                   int W, int M, int t0, int t1, int motion_only, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+  return ba_build_impl(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, E, nbuf, H, W, M, t0, t1,
+                       motion_only, workspace, workspace_bytes, stream, 0);
+}
+
+int droid_ba_build_packed(const float* poses, const float* disps, const float* intrinsics,
+                          const float* disps_sens, const float* targets, const float* weights,
+                          const float* eta, const int64_t* ii, const int64_t* jj, int E, int nbuf, int H,
+                          int W, int M, int t0, int t1, int motion_only, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  return ba_build_impl(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, E, nbuf, H, W, M, t0, t1,
+                       motion_only, workspace, workspace_bytes, stream, 1);
+}
+
+double* droid_ba_packed_system(void* workspace, int E, int nbuf, int H, int W, int t0, int t1, int M,
+                               size_t* n_elements) {
+  BaView v;
+  if (!workspace || t1 <= t0) return nullptr;
+  ba_carve(v, workspace, E, nbuf, H, W, t0, t1, M);
+  if (n_elements) *n_elements = packed_offset(v.n + 1);
+  return v.psys;
+}
+
+int droid_ba_unpack_system(int E, int nbuf, int H, int W, int M, int t0, int t1, int motion_only, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  BaView v;
+  int rc = ba_view(v, workspace, workspace_bytes, E, nbuf, H, W, t0, t1, M, motion_only);
+  if (rc) return rc;
+  launch_unpack_system(v, (hipStream_t)stream);
+  return check_hip("ba_unpack_system");
 }
 
 int droid_ba_solve_update(float* poses, float* disps, const float* intrinsics, const float* weights,

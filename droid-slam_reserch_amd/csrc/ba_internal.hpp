@@ -30,6 +30,13 @@ __host__ __device__ inline size_t chol_mbuf_offset(int n) { return ((size_t)(n +
 __host__ __device__ inline size_t chol_lfin_offset(int n) { return 2 * chol_mbuf_offset(n); }
 __host__ __device__ inline size_t chol_ldiag_doubles(int n) { return chol_lfin_offset(n) + chol_tiles(n) * CHOL_NB * CHOL_NB; }
 
+// Packed lower triangle + rhs row: row i holds columns 0..i in (i + 2) & ~1 doubles (16-byte aligned rows);
+// row n = rhs.  packed_offset(i) = sum of the lengths of rows < i; packed_offset(n + 1) = total.
+__host__ __device__ inline size_t packed_offset(int i) {
+  const size_t m = (size_t)(i >> 1);
+  return 2 * m * (m + 1) + ((i & 1) ? 2 * m + 2 : 0);
+}
+
 enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4, HDR_WORDS = 16 };
 enum { STATUS_BAD_INDEX = 1, STATUS_ETA_ROWS = 2, STATUS_CHOL_FAIL = 4, STATUS_CHOL_STALL = 8 };
 
@@ -65,6 +72,9 @@ struct BaView {
   int zsplit;              // linearisation: workgroups per (slot, pixel chunk), each takes a range of the slot's edges
   float* zpart;            // zsplit > 1: [zsplit][M][8][HW] partial C, w and self-row sums of those workgroups
   double* sys;             // [n+1][ld] reduced camera system, lower triangle, row n = rhs
+  double* psys;            // the same entries packed (rows of i+1 values rounded up to even, then the rhs row):
+                           // what a rank's build phase accumulates into when the systems are all-reduced
+  int packed;              // 1: the build kernels add into psys (multi-GPU), 0: straight into sys
   double* xsol;            // [ld] solve scratch / solution
   float* dx;               // [P][6]
   int* bs_flags;           // [chol_flag_words(n)] hand-off flags of the single-launch factorisation
@@ -131,6 +141,8 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
     v.Gpart = static_cast<double*>(take(sizeof(double) * (tiles * v.s2_split * 256 + 64)));
   }
   v.sys = static_cast<double*>(take(sizeof(double) * ((size_t)(v.n + 1) * v.ld + 8)));
+  v.psys = static_cast<double*>(take(sizeof(double) * (packed_offset(v.n + 1) + 8)));
+  v.packed = 0;
   v.xsol = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld + 1)));
   v.bs_flags = static_cast<int*>(take(sizeof(int) * chol_flag_words(v.n)));   // directly after xsol: one fill presets both
   v.ldiag = static_cast<double*>(take(sizeof(double) * chol_ldiag_doubles(v.n)));
@@ -150,6 +162,8 @@ __host__ __device__ inline int solver_preset_tiles(const BaView& v) { return v.n
 
 // kernels' launchers (ba_kernels.hip / chol.hip)
 void launch_prep(const BaView& v, const int64_t* ii, const int64_t* jj, hipStream_t s);
+// multi-GPU: expand the (all-reduced) packed system into the pitched matrix the solver factors in place
+void launch_unpack_system(const BaView& v, hipStream_t s);
 void launch_build(const BaView& v, const float* poses, const float* disps, const float* intr,
                   const float* sens, const float* targets, const float* weights, const float* eta,
                   const int64_t* ii, const int64_t* jj, bool motion_only, hipStream_t s);

@@ -99,6 +99,11 @@ __device__ __forceinline__ int reduce32_index(int lane) {
          (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4);
 }
 
+// Address of entry (gi, gj), gj <= gi, of the reduced camera system (row n = rhs) for the build kernels' atomics
+__device__ __forceinline__ double* sys_at(const BaView& v, int gi, int gj) {
+  return v.packed ? v.psys + packed_offset(gi) + gj : v.sys + (size_t)gi * v.ld + gj;
+}
+
 // Per-edge metadata of one depth slot, resident in LDS for the lifetime of a workgroup, so that
 // the per-pixel loops never chase seg_edge -> jj -> poses through dependent global loads.
 constexpr int SLOT_MAXE = 128;  // edges per metadata chunk (slots with more are processed in chunks)
@@ -342,6 +347,13 @@ __global__ __launch_bounds__(LIN_THREADS, 3) void ba_lin_kernel(
     // and the fill launch in front of it is gone
     if (blockIdx.y != 0 || blockIdx.z != 0) return;
     const int nz = (int)gridDim.x - zero_base;
+    if (v.packed) {
+      double2* p = reinterpret_cast<double2*>(v.psys);
+      const size_t n2 = packed_offset(v.n + 1) / 2;
+      for (size_t c = (size_t)((int)blockIdx.x - zero_base) * LIN_THREADS + tid; c < n2; c += (size_t)nz * LIN_THREADS)
+        p[c] = make_double2(0.0, 0.0);
+      return;
+    }
     for (int row = (int)blockIdx.x - zero_base; row <= v.n; row += nz) {
       double2* p = reinterpret_cast<double2*>(v.sys + (size_t)row * v.ld);
       const int n2 = (row == v.n) ? v.ld / 2 : (row + 2) / 2;   // 16-byte units covering columns 0..row
@@ -639,8 +651,7 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaView v, const float* 
     for (int r = 0; r < 6; r++) A[r][k] = Y[r];
   }
   __syncthreads();
-  const int n = v.n, ld = v.ld;
-  double* S = v.sys;
+  const int n = v.n;
   if (t < 36) {
     const int r = t / 6, c = t % 6;
     double s = 0.0;
@@ -650,25 +661,25 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaView v, const float* 
   __syncthreads();
   if (t < 36) {
     const int r = t / 6, c = t % 6;
-    if (vj_ok && r >= c) atomicAdd(&S[(size_t)(6 * pj + r) * ld + 6 * pj + c], hj[r][c]);
+    if (vj_ok && r >= c) atomicAdd(sys_at(v, 6 * pj + r, 6 * pj + c), hj[r][c]);
     if (vi_ok && r >= c) {
       double s = 0.0;
       for (int k = 0; k < 6; k++) s -= hij[r][k] * A[c][k];  // Hii = A Hjj A^T = -Hij A^T
-      atomicAdd(&S[(size_t)(6 * pi + r) * ld + 6 * pi + c], s);
+      atomicAdd(sys_at(v, 6 * pi + r, 6 * pi + c), s);
     }
     if (vi_ok && vj_ok) {
       if (pi > pj)
-        atomicAdd(&S[(size_t)(6 * pi + r) * ld + 6 * pj + c], hij[r][c]);
+        atomicAdd(sys_at(v, 6 * pi + r, 6 * pj + c), hij[r][c]);
       else  // Hji = Hij^T lands in the lower triangle
-        atomicAdd(&S[(size_t)(6 * pj + c) * ld + 6 * pi + r], hij[r][c]);
+        atomicAdd(sys_at(v, 6 * pj + c, 6 * pi + r), hij[r][c]);
     }
   } else if (t >= 40 && t < 46) {
     const int r = t - 40;
-    if (vj_ok) atomicAdd(&S[(size_t)n * ld + 6 * pj + r], vj[r]);
+    if (vj_ok) atomicAdd(sys_at(v, n, 6 * pj + r), vj[r]);
     if (vi_ok) {
       double s = 0.0;
       for (int k = 0; k < 6; k++) s -= A[r][k] * vj[k];  // vi = -A vj
-      atomicAdd(&S[(size_t)n * ld + 6 * pi + r], s);
+      atomicAdd(sys_at(v, n, 6 * pi + r), s);
     }
   }
 }
@@ -959,17 +970,17 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
             const double val = -tot[t][x];
             const int gj = 6 * (MULTI ? v.ent_pose[e0 + lj / 6] : s_pose[lj / 6]) + lj % 6;
             if (li == R) {  // w row: reduced rhs
-              atomicAdd(&v.sys[(size_t)v.n * v.ld + gj], val);
+              atomicAdd(sys_at(v, v.n, gj), val);
               continue;
             }
             const int gi = 6 * (MULTI ? v.ent_pose[e0 + li / 6] : s_pose[li / 6]) + li % 6;
             const bool diag_tile = (ba == bb) && (ta == tb);
             if (diag_tile) {  // both (li,lj) and (lj,li) are computed
-              if (gi >= gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
+              if (gi >= gj) atomicAdd(sys_at(v, gi, gj), val);
             } else {  // the mirror element is not computed: fold it into the lower triangle
-              if (gi > gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
-              else if (gi < gj) atomicAdd(&v.sys[(size_t)gj * v.ld + gi], val);
-              else atomicAdd(&v.sys[(size_t)gi * v.ld + gj], 2.0 * val);
+              if (gi > gj) atomicAdd(sys_at(v, gi, gj), val);
+              else if (gi < gj) atomicAdd(sys_at(v, gj, gi), val);
+              else atomicAdd(sys_at(v, gi, gj), 2.0 * val);
             }
           }
         }
@@ -1301,8 +1312,7 @@ __global__ __launch_bounds__(1024) void ba_schur_fold_kernel(BaView v, const flo
   }
   // 3. scatter: entries = window edges (+ the self entry, index nedges)
   const int nrow = R + (has_self ? 6 : 0);
-  double* S = v.sys;
-  const int n = v.n, ld = v.ld;
+  const int n = v.n;
   for (int o = tid; o < nrow * nrow; o += 1024) {
     const int ia = o / nrow, ib = o % nrow;
     const int a = ia / 6, r = ia % 6, b = ib / 6, c = ib % 6;
@@ -1315,14 +1325,14 @@ __global__ __launch_bounds__(1024) void ba_schur_fold_kernel(BaView v, const flo
     else if (a == nedges && b == nedges) val = Sss[r][c];
     else if (a == nedges) val = Vs[b][r][c];
     else val = Vs[a][c][r];
-    atomicAdd(&S[(size_t)gi * ld + gj], -val);
+    atomicAdd(sys_at(v, gi, gj), -val);
   }
   for (int o = tid; o < nrow; o += 1024) {
     const int a = o / 6, r = o % 6;
     const int pa = (a == nedges) ? pf : s_pose[a];
     if (pa < 0) continue;
     const double val = (a == nedges) ? us[r] : G[R * S2_GP + o];
-    atomicAdd(&S[(size_t)n * ld + 6 * pa + r], -val);
+    atomicAdd(sys_at(v, n, 6 * pa + r), -val);
   }
 }
 
@@ -1487,16 +1497,16 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
           const double val = -(double)acc[u][q][x];
           const int gj = 6 * s_pose[lj / 6] + lj % 6;
           if (li == R) {  // w row: reduced rhs
-            atomicAdd(&v.sys[(size_t)v.n * v.ld + gj], val);
+            atomicAdd(sys_at(v, v.n, gj), val);
             continue;
           }
           const int gi = 6 * s_pose[li / 6] + li % 6;
           if (ta == tb) {  // diagonal tile: both (li,lj) and (lj,li) are computed
-            if (gi >= gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
+            if (gi >= gj) atomicAdd(sys_at(v, gi, gj), val);
           } else {  // the mirror element is not computed: fold it into the lower triangle
-            if (gi > gj) atomicAdd(&v.sys[(size_t)gi * v.ld + gj], val);
-            else if (gi < gj) atomicAdd(&v.sys[(size_t)gj * v.ld + gi], val);
-            else atomicAdd(&v.sys[(size_t)gi * v.ld + gj], 2.0 * val);
+            if (gi > gj) atomicAdd(sys_at(v, gi, gj), val);
+            else if (gi < gj) atomicAdd(sys_at(v, gj, gi), val);
+            else atomicAdd(sys_at(v, gi, gj), 2.0 * val);
           }
         }
       }
@@ -1642,9 +1652,23 @@ __global__ void ba_pose_retr_kernel(BaView v, float* __restrict__ poses, const d
   for (int n = 0; n < 4; n++) poses[7 * k + 3 + n] = qn[n];
 }
 
+// multi-GPU: psys (packed, all-reduced over the ranks) -> sys (pitched, what the solver factors in place)
+__global__ __launch_bounds__(256) void ba_unpack_kernel(BaView v) {
+  for (int row = blockIdx.x; row <= v.n; row += gridDim.x) {
+    const double2* src = reinterpret_cast<const double2*>(v.psys + packed_offset(row));
+    double2* dst = reinterpret_cast<double2*>(v.sys + (size_t)row * v.ld);
+    const int n2 = (row == v.n) ? (v.n + 1) / 2 : (row + 2) / 2;
+    for (int c = threadIdx.x; c < n2; c += 256) dst[c] = src[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
+void launch_unpack_system(const BaView& v, hipStream_t s) {
+  if (v.n > 0) hipLaunchKernelGGL(ba_unpack_kernel, dim3(min(v.n + 1, 1024)), dim3(256), 0, s, v);
+}
+
 void launch_prep(const BaView& v, const int64_t* ii, const int64_t* jj, hipStream_t s) {
   hipLaunchKernelGGL(ba_prep_kernel, dim3(1), dim3(1024), 0, s, v, ii, jj);
 }
@@ -1673,7 +1697,8 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
         hipLaunchKernelGGL((ba_lin_kernel<false, false, false>), dim3(v.E + ZB, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
                            disps, intr, sens, targets, weights, eta, ii, jj, v.E);
       } else {
-        (void)hipMemsetAsync(v.sys, 0, sizeof(double) * (size_t)(v.n + 1) * v.ld, s);
+        if (v.packed) (void)hipMemsetAsync(v.psys, 0, sizeof(double) * packed_offset(v.n + 1), s);
+        else (void)hipMemsetAsync(v.sys, 0, sizeof(double) * (size_t)(v.n + 1) * v.ld, s);
       }
       break;
     }

@@ -17,7 +17,8 @@ SYMBOLS = [
     "droid_abi_version", "droid_last_error",
     "droid_corr_index_forward", "droid_corr_index_backward",
     "droid_altcorr_forward", "droid_altcorr_backward", "droid_altcorr_pyramid_forward",
-    "droid_ba_workspace_bytes", "droid_ba", "droid_ba_prepare", "droid_ba_build",
+    "droid_ba_workspace_bytes", "droid_ba", "droid_ba_prepare", "droid_ba_build", "droid_ba_build_packed",
+    "droid_ba_packed_system", "droid_ba_unpack_system",
     "droid_ba_solve_update", "droid_ba_profile_iteration", "droid_ba_system", "droid_ba_status",
     "droid_ba_attach_status_mirror", "droid_chol_solve", "droid_chol_scratch_doubles", "droid_reproject_motion",
     "droid_frame_distance", "droid_frame_distance_matrix", "droid_projmap", "droid_iproj", "droid_depth_filter",
@@ -59,6 +60,10 @@ def load() -> ctypes.CDLL:
     lib.droid_ba.argtypes = [vp] * 9 + [c_int] * 8 + [c_float, c_float, c_int, vp, vp, vp, sz, vp]
     lib.droid_ba_prepare.argtypes = [vp, vp] + [c_int] * 10 + [vp, sz, vp]
     lib.droid_ba_build.argtypes = [vp] * 9 + [c_int] * 8 + [vp, sz, vp]
+    lib.droid_ba_build_packed.argtypes = [vp] * 9 + [c_int] * 8 + [vp, sz, vp]
+    lib.droid_ba_packed_system.argtypes = [vp] + [c_int] * 7 + [ctypes.POINTER(sz)]
+    lib.droid_ba_packed_system.restype = vp
+    lib.droid_ba_unpack_system.argtypes = [c_int] * 8 + [vp, sz, vp]
     lib.droid_ba_solve_update.argtypes = [vp] * 6 + [c_int] * 7 + [c_float, c_float, c_int, vp, vp, vp, sz, vp]
     lib.droid_ba_profile_iteration.argtypes = [vp] * 9 + [c_int] * 7 + [c_float, c_float, c_int, vp, sz, vp, vp]
     lib.droid_ba_system.argtypes = [vp] + [c_int] * 7 + [ctypes.POINTER(sz)]
@@ -75,7 +80,7 @@ def load() -> ctypes.CDLL:
     lib.droid_iproj.argtypes = [vp] * 3 + [c_int] * 3 + [vp, vp]
     lib.droid_depth_filter.argtypes = [vp] * 5 + [c_int] * 4 + [vp, vp]
     for s in SYMBOLS[2:]:
-        if s not in ("droid_ba_workspace_bytes", "droid_ba_system", "droid_chol_scratch_doubles"):
+        if s not in ("droid_ba_workspace_bytes", "droid_ba_system", "droid_ba_packed_system", "droid_chol_scratch_doubles"):
             getattr(lib, s).restype = c_int
     if lib.droid_abi_version() != 1:
         raise DroidBackendError("ABI version mismatch")

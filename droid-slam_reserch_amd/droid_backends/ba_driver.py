@@ -88,6 +88,10 @@ class HipBackend:
         ptr = self.lib.droid_ba_system(self.ws.data_ptr(), E, nbuf, H, W, t0, t1, M, ctypes.byref(nel))
         off = ptr - self.ws.data_ptr()
         self.system = self.ws[off:off + nel.value * 8].view(torch.float64)
+        nel = ctypes.c_size_t(0)
+        ptr = self.lib.droid_ba_packed_system(self.ws.data_ptr(), E, nbuf, H, W, t0, t1, M, ctypes.byref(nel))
+        off = ptr - self.ws.data_ptr()
+        self.packed = self.ws[off:off + nel.value * 8].view(torch.float64)   # lower triangle + rhs row, contiguous
         self.dx = torch.empty((t1 - t0, 6), dtype=torch.float32, device=p.poses.device)
         self.dz = torch.empty((M, H * W), dtype=torch.float32, device=p.poses.device)
         self._ridx_key = (t1 - t0, nel.value)
@@ -116,6 +120,23 @@ class HipBackend:
                                            E, nbuf, H, W, M, t0, t1, int(motion_only), self.ws.data_ptr(),
                                            self.ws.numel(), s), "ba_build")
         return self.system
+
+    def build_packed(self, p: BAProblemDev, motion_only):
+        """Multi-GPU build phase: the contribution of this rank lands in `self.packed` (what gets all-reduced)."""
+        E, nbuf, H, W, M, t0, t1 = self._dims
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.lib.droid_ba_build_packed(p.poses.data_ptr(), p.disps.data_ptr(), p.intrinsics.data_ptr(),
+                                                  p.disps_sens.data_ptr(), p.targets.data_ptr(), p.weights.data_ptr(),
+                                                  p.eta.data_ptr() if M > 0 else None, p.ii.data_ptr(), p.jj.data_ptr(),
+                                                  E, nbuf, H, W, M, t0, t1, int(motion_only), self.ws.data_ptr(),
+                                                  self.ws.numel(), s), "ba_build_packed")
+        return self.packed
+
+    def unpack(self, motion_only):
+        E, nbuf, H, W, M, t0, t1 = self._dims
+        _lib.check(self.lib.droid_ba_unpack_system(E, nbuf, H, W, M, t0, t1, int(motion_only), self.ws.data_ptr(),
+                                                   self.ws.numel(), torch.cuda.current_stream().cuda_stream),
+                   "ba_unpack_system")
 
     def solve_update(self, p: BAProblemDev, lm, ep, motion_only):
         E, nbuf, H, W, M, t0, t1 = self._dims
@@ -169,16 +190,23 @@ class ShardedBA:
         be = self.backend
         be.prepare(p, t0, t1, own, motion_only)
         for _ in range(int(iterations)):
-            system = be.build(p, motion_only)
-            if world > 1:
-                ridx = be.reduce_index() if hasattr(be, "reduce_index") else None
-                if ridx is None:
-                    dist.all_reduce(system, op=dist.ReduceOp.SUM, group=self.group)
-                else:  # only what the solve reads: lower triangle + rhs row, packed
-                    flat = system.view(-1)
-                    packed = flat.index_select(0, ridx)
-                    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
-                    flat.index_copy_(0, ridx, packed)
+            if world > 1 and hasattr(be, "build_packed"):
+                # the build kernels add straight into the packed triangle: one collective on a contiguous tensor,
+                # then ONE extra launch (unpack) in front of the solve -- no gather / scatter of the triangle
+                packed = be.build_packed(p, motion_only)
+                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+                be.unpack(motion_only)
+            else:
+                system = be.build(p, motion_only)
+                if world > 1:
+                    ridx = be.reduce_index() if hasattr(be, "reduce_index") else None
+                    if ridx is None:
+                        dist.all_reduce(system, op=dist.ReduceOp.SUM, group=self.group)
+                    else:  # only what the solve reads: lower triangle + rhs row, packed
+                        flat = system.view(-1)
+                        packed = flat.index_select(0, ridx)
+                        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+                        flat.index_copy_(0, ridx, packed)
             be.solve_update(p, lm, ep, motion_only)
         return be.dx
 

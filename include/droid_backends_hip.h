@@ -125,6 +125,22 @@ int droid_ba_build(const float *poses, const float *disps, const float *intrinsi
                    int W, int M, int t0, int t1, int motion_only, void *workspace,
                    size_t workspace_bytes, void *stream);
 
+/* Multi-GPU variant of the build phase: the rank's contribution goes to a PACKED copy of the system -- row i
+ * (0 <= i < 6P) holds columns 0..i in (i + 2) & ~1 doubles, the rhs row follows, rows are 16-byte aligned --
+ * which droid_ba_packed_system() exposes as one contiguous fp64 tensor of *n_elements values: all-reduce (sum) it
+ * over the ranks as it is (half the bytes of the pitched matrix, no gather / scatter of the triangle), then call
+ * droid_ba_unpack_system (one launch: packed -> the pitched matrix the solver factors in place) and
+ * droid_ba_solve_update.  Argument meaning as droid_ba_build. */
+int droid_ba_build_packed(const float *poses, const float *disps, const float *intrinsics,
+                          const float *disps_sens, const float *targets, const float *weights,
+                          const float *eta, const int64_t *ii, const int64_t *jj, int E, int nbuf, int H,
+                          int W, int M, int t0, int t1, int motion_only, void *workspace,
+                          size_t workspace_bytes, void *stream);
+double *droid_ba_packed_system(void *workspace, int E, int nbuf, int H, int W, int t0, int t1, int M,
+                               size_t *n_elements);
+int droid_ba_unpack_system(int E, int nbuf, int H, int W, int M, int t0, int t1, int motion_only,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 int droid_ba_solve_update(float *poses, float *disps, const float *intrinsics, const float *weights,
                           const int64_t *ii, const int64_t *jj, int E, int nbuf, int H, int W, int M,
                           int t0, int t1, float lm, float ep, int motion_only, float *dx_out,
