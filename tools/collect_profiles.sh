@@ -1,9 +1,14 @@
+# The rocprofv3 passes behind profiles/r02_*: kernel stats of the default bench command, FETCH_SIZE and WRITE_SIZE in
+# separate --pmc passes (no trace domains mixed in), then the plain bench line.  Run on the GPU box: bash tools/collect_profiles.sh
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --steps 16 --warmup 3 > $R/gpurun_out/prof_stats.log 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_fetch.log 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $R/gpurun_out/prof_write -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_write.log 2>&1
-cd $R && python tools/pmc_summary.py gpurun_out/pmc_summary.json gpurun_out/prof_fetch gpurun_out/prof_write > gpurun_out/pmc_summary.txt
-python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-tail -c 600 gpurun_out/bench_final.json
+O=$R/gpurun_out/r02prof
+mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 16 --warmup 3 --no-extra > $O/stats.json 2> $O/stats.err
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/fetch -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-extra > $O/fetch.json 2> $O/fetch.err
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/write -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-extra > $O/write.json 2> $O/write.err
+cd $R && python3 tools/pmc_summary.py $O/pmc_summary.json $O/fetch $O/write > $O/pmc_summary.txt
+cp $(ls $O/stats/*/*kernel_stats.csv | tail -1) $O/kernel_stats.csv
+python3 bench.py > $O/bench.json 2> $O/bench.err
+tail -c 400 $O/bench.json
