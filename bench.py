@@ -439,10 +439,11 @@ def main():
             flop("droid::chol_factor_persistent_kernel", "factor", n ** 3 / 3.0, FP64_VEC_PEAK_TFLOPS,
                  "fp64 Cholesky of the (6P)^2 reduced camera system in one launch, n^3/3 flops over ceil(n/64) "
                  "dependent block columns: a pivot-latency chain, priced against the fp64 vector/MFMA peak"),
-            hbm("droid::ba_lin_kernel<true>", "linearize", 16.0 * E_l * HW + 16.0 * M_l * HW + 56.0 * Nk,
+            hbm("droid::ba_lin_kernel<true, false, false>", "linearize", 16.0 * E_l * HW + 16.0 * M_l * HW + 56.0 * Nk,
                 "compulsory bytes of one BA iteration (16*E*HW + 16*M*HW + 56*N)"),
-            flop("droid::ba_schur_fused_kernel<false>", "schur", schur_flops, 157.3,
-                 "Schur SYRK, symmetric-minimum flops, fp32 MFMA peak; the kernel also recomputes the E rows"),
+            flop("droid::ba_schur2_kernel", "schur", schur_flops, 157.3,
+                 "Schur SYRK (+ per-slot fold kernel, in the stage time), symmetric-minimum flops, fp32 MFMA peak; the kernel "
+                 "also recomputes the E rows; fp32 MFMA and VALU time add up on gfx950 (tools/micro/mfma_valu_overlap.hip)"),
             hbm("droid::ba_backsub_kernel", "update", 8.0 * E_l * HW + 16.0 * M_l * HW,
                 "weights (8*E*HW) + Q, w, disps r/w (16*M*HW)"),
         ]
