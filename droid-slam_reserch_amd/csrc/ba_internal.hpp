@@ -59,6 +59,7 @@ struct BaView {
   int* ent_pose;           // [M+E] pose index in the window
   int* wk_ptr;             // [nbuf+1] scratch (slot sizes while sorting)
   int* order;              // [nbuf+1] slots sorted by descending edge count: big slots are dispatched first
+  int* xtmp;               // [3(E+1)] prep scratch: unsorted segment fill, window flag and slot of every sorted position
   int* gt_ptr;             // [nbuf+2] first partial-sum tile of a slot served by ba_schur2_kernel (exclusive scan)
   double* Gpart;           // [tiles][s2_split][256] fp64 partial sums of those slots' Gram tiles, one per pixel range
   int s2_split;            // pixel ranges per slot of ba_schur2_kernel
@@ -111,6 +112,7 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.wk_ptr = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
   v.order = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
   v.gt_ptr = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
+  v.xtmp = static_cast<int*>(take(sizeof(int) * 3 * ((size_t)E + 1)));
   v.Hpart = static_cast<float*>(take(sizeof(float) * ((size_t)E * v.nch * 32 + 32)));
   v.Q = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
   v.w = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));
