@@ -183,6 +183,15 @@ def bench_corr(args, rank, world, dev, prob):
                                 algorithmic_bytes_per_pix=vol_bytes_per_pix,
                                 hbm_gbs=pix * vol_bytes_per_pix / ms_vol / 1e6,
                                 frac_of_8TBs=pix * vol_bytes_per_pix / ms_vol / 1e6 / HBM_PEAK_GBS))
+    # the caller's whole CorrBlock.__call__ (4 lookups at coords / 2**l + torch.cat, modules/corr.py:45-50) against the
+    # one-call variant that writes the concatenated tensor directly
+    def run_call():
+        return torch.cat([db.corr_index_forward(pyramid[lvl], cq / 2 ** lvl, r)[0].view(B, -1, H, W) for lvl in range(4)], dim=1)
+    ms_call = timeit(run_call, 5)
+    ms_fused = timeit(lambda: db.corr_pyramid_forward(pyramid, cq, r), 5)
+    out["volume_fp16"]["corrblock_call_ms"] = ms_call
+    out["volume_fp16"]["corr_pyramid_forward_ms"] = ms_fused
+    out["volume_fp16"]["corr_pyramid_forward_gpix_per_s"] = pix / ms_fused / 1e6
     # alt-corr: channels-last fp32 pyramid of pooled fmaps (modules/corr.py:92-125)
     Ba = min(B, 64)
     fml = fm.float() / 4.0

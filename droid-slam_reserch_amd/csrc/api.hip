@@ -15,6 +15,8 @@ namespace droid {
 // corr.hip
 int launch_corr_index_forward(const void* volume, const float* coords, void* corr, int B, int H1,
                               int W1, int H2, int W2, int r, int dtype, hipStream_t s);
+int launch_corr_pyramid_forward(const void* const* volumes, const float* coords, void* corr, int B, int H1, int W1,
+                                int r, int levels, int dtype, hipStream_t s);
 int launch_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad, int B,
                                int H1, int W1, int H2, int W2, int r, int dtype, hipStream_t s);
 int launch_altcorr_pyramid_forward(const float* const* levels_dev, const int64_t* ii, const int64_t* jj,
@@ -91,6 +93,19 @@ int droid_corr_index_forward(const void* volume, const float* coords, void* corr
                                      (hipStream_t)stream);
   if (rc) return fail(rc, "corr_index_forward: %s", "unsupported configuration");
   return check_hip("corr_index_forward");
+}
+
+int droid_corr_pyramid_forward(const void* const* volumes, const float* coords, void* corr, int B, int H1, int W1,
+                               int radius, int levels, int dtype, void* stream) {
+  if (B < 0 || H1 <= 0 || W1 <= 0 || levels < 1) return fail(DROID_E_ARG, "corr_pyramid_forward: bad %s", "shape");
+  if (dtype < DROID_F16 || dtype > DROID_F64) return fail(DROID_E_ARG, "corr_pyramid_forward: bad %s", "dtype");
+  if (B == 0) return DROID_OK;
+  if (!volumes || !coords || !corr) return fail(DROID_E_ARG, "corr_pyramid_forward: null %s", "pointer");
+  for (int l = 0; l < levels; l++)
+    if (!volumes[l]) return fail(DROID_E_ARG, "corr_pyramid_forward: null %s", "pyramid level");
+  int rc = launch_corr_pyramid_forward(volumes, coords, corr, B, H1, W1, radius, levels, dtype, (hipStream_t)stream);
+  if (rc) return fail(rc, "corr_pyramid_forward: %s", "unsupported configuration (radius 3 or 4, levels that divide the map)");
+  return check_hip("corr_pyramid_forward");
 }
 
 int droid_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad, int B,

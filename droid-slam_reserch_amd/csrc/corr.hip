@@ -130,18 +130,22 @@ struct RowLoad<double, NT> {
   static __device__ __forceinline__ size_t span_bytes() { return NT * 8; }
 };
 
+// out_bstride: elements between the outputs of consecutive batch entries ((2r+1)^2 H1W1 for the reference's operator;
+// levels (2r+1)^2 H1W1 when the levels of a pyramid are written side by side, corr_pyramid_forward); cscale: the
+// coordinates are multiplied by it first (1, or 2^-level: exact).
 template <typename T, int R>
 __global__ __launch_bounds__(256) void corr_index_forward_kernel(const T* __restrict__ volume,
                                                                  const float* __restrict__ coords,
                                                                  T* __restrict__ corr, int H1W1,
-                                                                 int H2, int W2, size_t vol_elems) {
+                                                                 int H2, int W2, size_t vol_elems,
+                                                                 size_t out_bstride, float cscale) {
   typedef typename Elem<T>::work work;
   constexpr int RD = 2 * R + 1, NT = RD + 1;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (pix >= H1W1) return;
-  const float x0 = coords[((size_t)b * 2 + 0) * H1W1 + pix];
-  const float y0 = coords[((size_t)b * 2 + 1) * H1W1 + pix];
+  const float x0 = coords[((size_t)b * 2 + 0) * H1W1 + pix] * cscale;
+  const float y0 = coords[((size_t)b * 2 + 1) * H1W1 + pix] * cscale;
   const Bilin bl = bilin_setup(x0, y0, R);
   const T* plane = volume + ((size_t)b * H1W1 + pix) * ((size_t)H2 * W2);
   const uintptr_t vbeg = reinterpret_cast<uintptr_t>(volume);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void corr_index_forward_kernel(const T* __rest
   const work w01 = Elem<T>::round((work)f32_value((one - bl.dx) * bl.dy));          // tap (a  ,c+1)
   const work w10 = Elem<T>::round((work)f32_value(bl.dx * (one - bl.dy)));          // tap (a+1,c  )
   const work w11 = Elem<T>::round((work)f32_value(bl.dx * bl.dy));                  // tap (a+1,c+1)
-  T* out = corr + (size_t)b * RD * RD * H1W1 + pix;
+  T* out = corr + (size_t)b * out_bstride + pix;
 #pragma unroll
   for (int a = 0; a < RD; a++) {
 #pragma unroll
@@ -240,10 +244,11 @@ static int corr_index_forward_t(const void* volume, const float* coords, void* c
   const T* v = static_cast<const T*>(volume);
   T* c = static_cast<T*>(corr);
   const size_t vol_elems = (size_t)B * HW * H2 * W2;
+  const size_t obs = (size_t)(2 * r + 1) * (2 * r + 1) * HW;
   if (r == 3)
-    hipLaunchKernelGGL((corr_index_forward_kernel<T, 3>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems);
+    hipLaunchKernelGGL((corr_index_forward_kernel<T, 3>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems, obs, 1.0f);
   else if (r == 4)
-    hipLaunchKernelGGL((corr_index_forward_kernel<T, 4>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems);
+    hipLaunchKernelGGL((corr_index_forward_kernel<T, 4>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems, obs, 1.0f);
   else
     hipLaunchKernelGGL((corr_index_forward_generic<T>), grid, block, 0, s, v, coords, c, HW, H2, W2, r);
   return 0;
@@ -256,6 +261,42 @@ int launch_corr_index_forward(const void* volume, const float* coords, void* cor
     case DROID_F16: return corr_index_forward_t<__half>(volume, coords, corr, B, H1, W1, H2, W2, r, s);
     case DROID_F32: return corr_index_forward_t<float>(volume, coords, corr, B, H1, W1, H2, W2, r, s);
     case DROID_F64: return corr_index_forward_t<double>(volume, coords, corr, B, H1, W1, H2, W2, r, s);
+  }
+  return DROID_E_ARG;
+}
+
+// CorrBlock.__call__ (droid_slam/modules/corr.py:40-50) for all pyramid levels: level l looks up volumes[l]
+// ([B,H1,W1,H1>>l,W1>>l]) at coords * 2^-l and writes channels [l (2r+1)^2, (l+1) (2r+1)^2) of
+// corr [B, levels (2r+1)^2, H1, W1] -- the tensor torch.cat(out_pyramid, dim=2) would build, without the cat
+// (600 MB of extra traffic at 256 edges) and without the per-level coordinate tensors.  One launch per level.
+template <typename T>
+static int corr_pyramid_forward_t(const void* const* volumes, const float* coords, void* corr, int B, int H1, int W1,
+                                  int r, int levels, hipStream_t s) {
+  const int HW = H1 * W1, rd2 = (2 * r + 1) * (2 * r + 1);
+  dim3 grid((HW + 255) / 256, B), block(256);
+  const size_t obs = (size_t)levels * rd2 * HW;
+  for (int l = 0; l < levels; l++) {
+    const int H2 = H1 >> l, W2 = W1 >> l;
+    const T* v = static_cast<const T*>(volumes[l]);
+    T* c = static_cast<T*>(corr) + (size_t)l * rd2 * HW;
+    const size_t vol_elems = (size_t)B * HW * H2 * W2;
+    const float cs = 1.0f / (float)(1 << l);
+    if (r == 3)
+      hipLaunchKernelGGL((corr_index_forward_kernel<T, 3>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems, obs, cs);
+    else
+      hipLaunchKernelGGL((corr_index_forward_kernel<T, 4>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems, obs, cs);
+  }
+  return 0;
+}
+
+int launch_corr_pyramid_forward(const void* const* volumes, const float* coords, void* corr, int B, int H1, int W1,
+                                int r, int levels, int dtype, hipStream_t s) {
+  if (B > 65535 || (r != 3 && r != 4) || levels < 1 || levels > 8 || (H1 >> (levels - 1)) < 1 || (W1 >> (levels - 1)) < 1)
+    return DROID_E_ARG;
+  switch (dtype) {
+    case DROID_F16: return corr_pyramid_forward_t<__half>(volumes, coords, corr, B, H1, W1, r, levels, s);
+    case DROID_F32: return corr_pyramid_forward_t<float>(volumes, coords, corr, B, H1, W1, r, levels, s);
+    case DROID_F64: return corr_pyramid_forward_t<double>(volumes, coords, corr, B, H1, W1, r, levels, s);
   }
   return DROID_E_ARG;
 }

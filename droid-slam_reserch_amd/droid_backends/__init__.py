@@ -19,7 +19,8 @@ from ._lib import DroidBackendError  # noqa: F401
 
 __all__ = ["ba", "frame_distance", "projmap", "depth_filter", "iproj", "altcorr_forward",
            "altcorr_backward", "corr_index_forward", "corr_index_backward",
-           "altcorr_pyramid_forward", "reproject", "motion_features", "frame_distance_matrix"]  # the last four are additions
+           "altcorr_pyramid_forward", "reproject", "motion_features", "frame_distance_matrix",
+           "corr_pyramid_forward"]  # the last four are additions
 
 _DT = {torch.float16: _lib.DROID_F16, torch.float32: _lib.DROID_F32, torch.float64: _lib.DROID_F64}
 _workspaces = {}   # (device index, stream handle) -> _Workspace
@@ -325,6 +326,33 @@ def corr_index_forward(volume, coords, radius):
     _lib.check(lib.droid_corr_index_forward(volume.data_ptr(), coords.data_ptr(), corr.data_ptr(), B, H1, W1,
                                             H2, W2, r, _corr_dtype(volume, "volume"), _stream()),
                "corr_index_forward")
+    return [corr]
+
+
+def corr_pyramid_forward(pyramid, coords, radius):
+    """CorrBlock.__call__ (droid_slam/modules/corr.py:40-50) without the torch.cat: pyramid = CorrBlock.corr_pyramid
+    (list of [B,h,w,h>>l,w>>l] volumes of one dtype), coords [B,2,h,w] float32 at level-0 scale (the tensor __call__
+    builds at :43-44).  Returns [corr] with corr [B, levels*(2r+1)^2, h, w] = torch.cat([corr_index_forward(
+    pyramid[l], coords / 2**l, r).view(B, -1, h, w) for l], dim=1), bit for bit.  An addition."""
+    lib = _lib.load()
+    levels = list(pyramid)
+    for i, p in enumerate(levels):
+        _check_input(p, f"pyramid[{i}]")
+        if p.dtype != levels[0].dtype:
+            raise RuntimeError("corr_pyramid_forward: pyramid levels must share one dtype")
+    _check_f32(coords, "coords")
+    B, H1, W1 = int(levels[0].shape[0]), int(levels[0].shape[1]), int(levels[0].shape[2])
+    for l, p in enumerate(levels):
+        if tuple(p.shape) != (B, H1, W1, H1 >> l, W1 >> l):
+            raise RuntimeError(f"corr_pyramid_forward: pyramid[{l}] must be [{B},{H1},{W1},{H1 >> l},{W1 >> l}]")
+    if tuple(coords.shape) != (B, 2, H1, W1):
+        raise RuntimeError("corr_pyramid_forward: coords must be [B,2,H1,W1]")
+    r = int(radius)
+    rd2 = (2 * r + 1) ** 2
+    corr = torch.empty((B, len(levels) * rd2, H1, W1), dtype=levels[0].dtype, device=levels[0].device)
+    ptrs = (ctypes.c_void_p * len(levels))(*[p.data_ptr() for p in levels])
+    _lib.check(lib.droid_corr_pyramid_forward(ptrs, coords.data_ptr(), corr.data_ptr(), B, H1, W1, r, len(levels),
+                                              _corr_dtype(levels[0], "pyramid"), _stream()), "corr_pyramid_forward")
     return [corr]
 
 

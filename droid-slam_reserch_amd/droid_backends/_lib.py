@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("DROID_HIP_LIB") or os.path.join(_HERE, "libdroid_back
 # every symbol include/droid_backends_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
     "droid_abi_version", "droid_last_error",
-    "droid_corr_index_forward", "droid_corr_index_backward",
+    "droid_corr_index_forward", "droid_corr_index_backward", "droid_corr_pyramid_forward",
     "droid_altcorr_forward", "droid_altcorr_backward", "droid_altcorr_pyramid_forward",
     "droid_ba_workspace_bytes", "droid_ba", "droid_ba_prepare", "droid_ba_build", "droid_ba_build_packed",
     "droid_ba_packed_system", "droid_ba_unpack_system",
@@ -52,6 +52,7 @@ def load() -> ctypes.CDLL:
     lib.droid_last_error.restype = ctypes.c_char_p
     lib.droid_corr_index_forward.argtypes = [vp, vp, vp] + [c_int] * 7 + [vp]
     lib.droid_corr_index_backward.argtypes = [vp, vp, vp] + [c_int] * 7 + [vp]
+    lib.droid_corr_pyramid_forward.argtypes = [ctypes.POINTER(vp), vp, vp] + [c_int] * 6 + [vp]
     lib.droid_altcorr_forward.argtypes = [vp, vp, vp, vp] + [c_int] * 9 + [vp]
     lib.droid_altcorr_backward.argtypes = [vp] * 6 + [c_int] * 8 + [vp]
     lib.droid_altcorr_pyramid_forward.argtypes = [ctypes.POINTER(vp), vp, vp, vp, vp] + [c_int] * 7 + [vp]

@@ -50,6 +50,15 @@ const char *droid_last_error(void); /* thread-local message of the last failing 
 int droid_corr_index_forward(const void *volume, const float *coords, void *corr, int B, int H1,
                              int W1, int H2, int W2, int radius, int dtype, void *stream);
 
+/* CorrBlock.__call__ over all pyramid levels (droid_slam/modules/corr.py:40-50): level l looks
+ * up volumes[l] ([B,H1,W1,H1>>l,W1>>l], dtype) at coords * 2^-l (exact) and writes channels
+ * [l (2r+1)^2, (l+1) (2r+1)^2) of corr [B, levels (2r+1)^2, H1, W1] = torch.cat(out_pyramid, dim=2) of the
+ * reference (with its leading dimension of 1 dropped), without the cat and the per-level coordinate tensors.
+ * volumes: HOST array of `levels` device pointers; coords [B,2,H1,W1] f32 at level-0 scale.  Values are
+ * bit-identical to droid_corr_index_forward per level.  radius 3 or 4.  Not one of the reference's nine operators. */
+int droid_corr_pyramid_forward(const void *const *volumes, const float *coords, void *corr, int B, int H1,
+                               int W1, int radius, int levels, int dtype, void *stream);
+
 /* corr_index_backward (droid.cpp:180-191 -> correlation_kernels.cu:157-185).
  * corr_grad [B,2r+1,2r+1,H1,W1] dtype ; volume_grad [B,H1,W1,H2,W2] dtype (written completely). */
 int droid_corr_index_backward(const float *coords, const void *corr_grad, void *volume_grad, int B,

@@ -51,7 +51,7 @@ def test_python_mirror_has_the_reference_operators(backends):
     for name in ["ba", "frame_distance", "projmap", "depth_filter", "iproj", "altcorr_forward",
                  "altcorr_backward", "corr_index_forward", "corr_index_backward"]:
         assert callable(getattr(backends, name))
-    for name in ["altcorr_pyramid_forward", "reproject", "motion_features", "frame_distance_matrix"]:   # additions
+    for name in ["altcorr_pyramid_forward", "reproject", "motion_features", "frame_distance_matrix", "corr_pyramid_forward"]:   # additions
         assert callable(getattr(backends, name))
     from droid_backends import keyframes
     assert callable(keyframes.load) and callable(keyframes.save)

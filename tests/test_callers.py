@@ -80,6 +80,8 @@ def test_frontend_shaped_update(backends, oracle):
     corr = corr_op(coords1)                                               # [1,E,4*49,H,W] fp16
     assert corr.dtype == torch.float16 and tuple(corr.shape) == (1, E, 196, H, W)
     cflat = coords1.permute(0, 1, 4, 2, 3).contiguous().view(E, 2, H, W)
+    fused, = backends.corr_pyramid_forward(corr_op.pyramid, cflat, 3)
+    assert torch.equal(fused, corr[0])                                   # CorrBlock.__call__ without the cat
     for l in range(4):
         ref = oracle.corr_index_forward(corr_op.pyramid[l].cpu().numpy(), (cflat / 2 ** l).cpu().numpy(), 3)
         got = corr[0, :, 49 * l:49 * (l + 1)].reshape(E, 7, 7, H, W).cpu().numpy()

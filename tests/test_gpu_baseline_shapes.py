@@ -92,7 +92,11 @@ def test_cfg2_volume_lookup_48x64_four_levels_bit_exact(backends, oracle, cfg2_v
                           f"{np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()}"
         assert np.abs(ref.astype(np.float64)).max() > 0.1   # the comparison is not vacuous
         outs.append(out.view(1, 32, -1, 48, 64))
-    assert torch.cat(outs, dim=2).shape == (1, 32, 4 * 49, 48, 64)
+    cat = torch.cat(outs, dim=2)
+    assert cat.shape == (1, 32, 4 * 49, 48, 64)
+    # the one-call variant (no torch.cat, no per-level coordinate tensors) is the same tensor bit for bit
+    fused, = backends.corr_pyramid_forward([p.to(tdt).contiguous() for p in pyr], c, 3)
+    assert fused.dtype == tdt and torch.equal(fused, cat[0])
 
 
 def _alt_pyramid(torch, fmaps_f16):

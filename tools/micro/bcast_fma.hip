@@ -42,14 +42,15 @@ int main() {
   double* d; unsigned long long* c;
   (void)hipMalloc(&d, 64 * 8); (void)hipMalloc(&c, 64);
   const int reps = 2000;
-  k<<<1, 64>>>(d, c, reps);
-  k<<<1, 64>>>(d, c, reps);
-  (void)hipDeviceSynchronize();
-  unsigned long long h[3];
-  (void)hipMemcpy(h, c, 24, hipMemcpyDeviceToHost);
-  // s_memtime counts at 100 MHz
-  const double ops = 15.0 * reps;
-  printf("per column operation (s_memtime ticks are 10 ns): DPP fmac %.2f ns | 2x readlane + SGPR fma %.2f ns | plain v_fma_f64 %.2f ns\n",
-         h[0] * 10.0 / ops, h[1] * 10.0 / ops, h[2] * 10.0 / ops);
+  for (int lanes : {64, 32, 16}) {   // does a wave with only its first 16 / 32 lanes active issue faster?
+    k<<<1, lanes>>>(d, c, reps);
+    k<<<1, lanes>>>(d, c, reps);
+    (void)hipDeviceSynchronize();
+    unsigned long long h[3];
+    (void)hipMemcpy(h, c, 24, hipMemcpyDeviceToHost);
+    const double ops = 15.0 * reps;
+    printf("%2d active lanes: s_memtime ticks per column operation: DPP fmac %.2f | 2x readlane + SGPR fma %.2f | plain v_fma_f64 %.2f\n",
+           lanes, h[0] / ops, h[1] / ops, h[2] / ops);
+  }
   return 0;
 }
