@@ -86,6 +86,9 @@ __device__ __forceinline__ Bilin bilin_setup(float x0, float y0, int r) {
 // which made every line travel through L1/L2 2r+2 times.  Taps outside the plane are masked to 0
 // after the load (reading the neighbouring row of the same tensor is harmless); only lanes whose
 // wide load would leave the tensor fall back to per-element loads.
+#ifndef CORR_MINWG
+#define CORR_MINWG 1
+#endif
 typedef uint32_t u32a4 __attribute__((aligned(4)));
 
 template <typename T, int NT>
@@ -134,7 +137,7 @@ struct RowLoad<double, NT> {
 // levels (2r+1)^2 H1W1 when the levels of a pyramid are written side by side, corr_pyramid_forward); cscale: the
 // coordinates are multiplied by it first (1, or 2^-level: exact).
 template <typename T, int R>
-__global__ __launch_bounds__(256) void corr_index_forward_kernel(const T* __restrict__ volume,
+__global__ __launch_bounds__(256, CORR_MINWG) void corr_index_forward_kernel(const T* __restrict__ volume,
                                                                  const float* __restrict__ coords,
                                                                  T* __restrict__ corr, int H1W1,
                                                                  int H2, int W2, size_t vol_elems,
@@ -202,6 +205,86 @@ __global__ __launch_bounds__(256) void corr_index_forward_kernel(const T* __rest
   }
 }
 
+// Small planes (pyramid level 3 at 48x64: 96 bytes per query in fp16, 192 in fp32): the planes of the 64 queries of a wave
+// are contiguous in the volume, and the (2r+2)^2 window covers most or all of each, so the wave streams its 64 planes
+// with fully coalesced 16-byte loads into LDS (plane pitch + 4 bytes: the lanes' private planes fall into different
+// banks) and every lane gathers its taps from there.  Per-lane row loads straight from memory made the same lines pass
+// through the texture path once per window row and fetched 1.3-1.4x the volume (profiles/r01_corr_lookup_per_level.txt).
+// Arithmetic, rounding points and output layout are those of corr_index_forward_kernel.
+constexpr int CS_MAXPLANE = 192;  // bytes per plane served by this kernel.  Measured at 48x64, 256 / 128 edges: 96-byte planes
+                                  // (fp16 level 3) 37.6 -> 35.6 us, 192-byte planes (fp32 level 3) 39.2 -> 27.4 us; 384- and 768-byte
+                                  // planes (level 2) get SLOWER this way (88 -> 150 us, 64 -> 212 us: 25-49 KB of LDS per wave leave
+                                  // 3-6 waves per CU and nothing overlaps the load -> barrier -> gather sequence), so they keep the row loads
+template <typename T, int R>
+__global__ __launch_bounds__(64) void corr_index_forward_small(const T* __restrict__ volume,
+                                                               const float* __restrict__ coords,
+                                                               T* __restrict__ corr, int H1W1, int H2, int W2,
+                                                               size_t out_bstride, float cscale) {
+  typedef typename Elem<T>::work work;
+  constexpr int RD = 2 * R + 1, NT = RD + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int pix0 = blockIdx.x * 64, b = blockIdx.y;
+  const int nq = min(64, H1W1 - pix0);
+  const int PB = H2 * W2 * (int)sizeof(T);      // bytes per plane: a multiple of 16 (checked by the launcher)
+  const int pitch = PB + 4;
+  const unsigned char* src = reinterpret_cast<const unsigned char*>(volume + ((size_t)b * H1W1 + pix0) * ((size_t)H2 * W2));
+  const int nvec = (nq * PB) >> 4;
+  for (int u = lane; u < nvec; u += 64) {
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)u * 16);
+    const int byte = u * 16, p = byte / PB, off = byte - p * PB;
+    unsigned* d = reinterpret_cast<unsigned*>(smem + p * pitch + off);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  if (lane >= nq) return;
+  const int pix = pix0 + lane;
+  const float x0 = coords[((size_t)b * 2 + 0) * H1W1 + pix] * cscale;
+  const float y0 = coords[((size_t)b * 2 + 1) * H1W1 + pix] * cscale;
+  const Bilin bl = bilin_setup(x0, y0, R);
+  const T* plane = reinterpret_cast<const T*>(smem + lane * pitch);
+  work tap[NT][NT];  // [row j (y)][col i (x)]
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    const int y1 = bl.y1 + j;
+    const bool rowok = (y1 >= 0) && (y1 < H2);
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+      const int x1 = bl.x1 + i;
+      const bool ok = rowok && x1 >= 0 && x1 < W2;
+      tap[j][i] = ok ? Elem<T>::load(plane + (ok ? y1 * W2 + x1 : 0)) : (work)0;
+    }
+  }
+  const float one = 1.0f;
+  const work w00 = Elem<T>::round((work)f32_value((one - bl.dx) * (one - bl.dy)));  // tap (a  ,c  )   ck:55-65
+  const work w01 = Elem<T>::round((work)f32_value((one - bl.dx) * bl.dy));          // tap (a  ,c+1)
+  const work w10 = Elem<T>::round((work)f32_value(bl.dx * (one - bl.dy)));          // tap (a+1,c  )
+  const work w11 = Elem<T>::round((work)f32_value(bl.dx * bl.dy));                  // tap (a+1,c+1)
+  T* out = corr + (size_t)b * out_bstride + pix;
+#pragma unroll
+  for (int a = 0; a < RD; a++) {
+#pragma unroll
+    for (int c = 0; c < RD; c++) {
+      work acc = Elem<T>::mul(tap[c][a], w00);  // 0 + p == p exactly
+      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a], w01));
+      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c][a + 1], w10));
+      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a + 1], w11));
+      Elem<T>::store(out + (size_t)(a * RD + c) * H1W1, acc);
+    }
+  }
+}
+
+template <typename T, int R>
+static bool launch_corr_small(const T* v, const float* coords, T* c, int B, int HW, int H2, int W2, size_t obs,
+                              float cs, hipStream_t s) {
+  static const bool off = (getenv("DROID_CORR_NO_SMALL") != nullptr);  // diagnostics: the per-lane row-load kernel
+  const int PB = H2 * W2 * (int)sizeof(T);
+  if (off || PB > CS_MAXPLANE || (PB & 15) != 0 || (reinterpret_cast<uintptr_t>(v) & 15) != 0) return false;
+  hipLaunchKernelGGL((corr_index_forward_small<T, R>), dim3((HW + 63) / 64, B), dim3(64), 64 * (PB + 4), s, v, coords, c,
+                     HW, H2, W2, obs, cs);
+  return true;
+}
+
 // Any radius (slow path): taps are re-read per output.
 template <typename T>
 __global__ __launch_bounds__(256) void corr_index_forward_generic(const T* __restrict__ volume,
@@ -245,6 +328,8 @@ static int corr_index_forward_t(const void* volume, const float* coords, void* c
   T* c = static_cast<T*>(corr);
   const size_t vol_elems = (size_t)B * HW * H2 * W2;
   const size_t obs = (size_t)(2 * r + 1) * (2 * r + 1) * HW;
+  if (r == 3 && launch_corr_small<T, 3>(v, coords, c, B, HW, H2, W2, obs, 1.0f, s)) return 0;
+  if (r == 4 && launch_corr_small<T, 4>(v, coords, c, B, HW, H2, W2, obs, 1.0f, s)) return 0;
   if (r == 3)
     hipLaunchKernelGGL((corr_index_forward_kernel<T, 3>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems, obs, 1.0f);
   else if (r == 4)
@@ -281,6 +366,8 @@ static int corr_pyramid_forward_t(const void* const* volumes, const float* coord
     T* c = static_cast<T*>(corr) + (size_t)l * rd2 * HW;
     const size_t vol_elems = (size_t)B * HW * H2 * W2;
     const float cs = 1.0f / (float)(1 << l);
+    if (r == 3 && launch_corr_small<T, 3>(v, coords, c, B, HW, H2, W2, obs, cs, s)) continue;
+    if (r == 4 && launch_corr_small<T, 4>(v, coords, c, B, HW, H2, W2, obs, cs, s)) continue;
     if (r == 3)
       hipLaunchKernelGGL((corr_index_forward_kernel<T, 3>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems, obs, cs);
     else
