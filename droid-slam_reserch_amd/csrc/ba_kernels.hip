@@ -450,6 +450,7 @@ __global__ __launch_bounds__(LIN_THREADS, 3) void ba_lin_kernel(
 
   int pix[LIN_PPT];
   float disp[LIN_PPT], Cacc[LIN_PPT], wacc[LIN_PPT];
+  double X0d[LIN_PPT], X1d[LIN_PPT];  // back-projected pixel, fp64 (se3.hpp: linearize_pixel_d)
 #pragma unroll
   for (int p = 0; p < LIN_PPT; p++) {
     pix[p] = chunk * LIN_CP + p * LIN_THREADS + tid;
@@ -457,6 +458,9 @@ __global__ __launch_bounds__(LIN_THREADS, 3) void ba_lin_kernel(
     wacc[p] = 0.f;
     disp[p] = 0.f;
     if (DEPTH && pix[p] < HW) disp[p] = disps[(size_t)f * HW + pix[p]];
+    const int kk = pix[p] < HW ? pix[p] : 0;
+    X0d[p] = ((double)(kk % W) - (double)K.cx) / (double)K.fx;
+    X1d[p] = ((double)(kk / W) - (double)K.cy) / (double)K.fy;
   }
 
   float in_cur[LIN_PPT][4], in_nxt[LIN_PPT][4];  // target u,v and weight u,v of this thread's pixels
@@ -520,8 +524,7 @@ __global__ __launch_bounds__(LIN_THREADS, 3) void ba_lin_kernel(
       if (pix[p] < HW) {
         const int k = pix[p];
         const float d = DEPTH ? disp[p] : disps[(size_t)ix * HW + k];
-        const float u = (float)(k % W), vv = (float)(k / W);
-        const PixLin L = linearize_pixel_d(K, Rt, Rt + 9, u, vv, d, in_cur[p][0], in_cur[p][1]);
+        const PixLin L = linearize_pixel_d(K, Rt, Rt + 9, X0d[p], X1d[p], d, in_cur[p][0], in_cur[p][1]);
         float wu = L.valid * (0.001f * in_cur[p][2]);        // dk:305-306
         float wv = L.valid * (0.001f * in_cur[p][3]);
         if (DEPTH) {
@@ -761,9 +764,9 @@ constexpr int SF_PITCH = SF_TP + 4;   // 16-byte aligned rows, conflict-free 16-
 constexpr int SF_MAXT = 11;           // max 16x16 output tiles per wave: ceil(7*6/4)
 
 // E row (6 values) of one (edge, pixel); T = the edge's relative pose (R row-major, t)
-__device__ __forceinline__ void e_row(const Intr& K, const float* T, bool stereo, int k, int W, float disp,
+__device__ __forceinline__ void e_row(const Intr& K, const float* T, bool stereo, float X0, float X1, float disp,
                                       float wu_raw, float wv_raw, float* eij) {
-  const PixLin L = jacobians_pixel(K, T, T + 9, (float)(k % W), (float)(k / W), disp);
+  const PixLin L = jacobians_pixel(K, T, T + 9, X0, X1, disp);
   float wu = L.valid * (0.001f * wu_raw), wv = L.valid * (0.001f * wv_raw);
   if (stereo) {
     wu = 0.f;
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void ba_schur_fused_kernel(
                     wu_raw = wg[k];
                     wv_raw = wg[HW + k];
                   }
-                  e_row(K, T, sm.flag[x] != 0, k, W, disp, wu_raw, wv_raw, eij);
+                  e_row(K, T, sm.flag[x] != 0, ((float)(k % W) - K.cx) / K.fx, ((float)(k / W) - K.cy) / K.fy, disp, wu_raw, wv_raw, eij);
                 }
                 if (self_here) {
                   float eii[6];
@@ -1589,11 +1592,15 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
   const Intr K = {intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
   int kpix[BSUB_PPT];
   float disp[BSUB_PPT], acc[BSUB_PPT];
+  float bx0[BSUB_PPT], bx1[BSUB_PPT];  // back-projected pixel, once per pixel
 #pragma unroll
   for (int p = 0; p < BSUB_PPT; p++) {
     kpix[p] = (blockIdx.y * BSUB_PPT + p) * 256 + threadIdx.x;
     disp[p] = kpix[p] < HW ? disps[(size_t)f * HW + kpix[p]] : 0.f;
     acc[p] = 0.f;
+    const int kk = kpix[p] < HW ? kpix[p] : 0;
+    bx0[p] = ((float)(kk % v.W) - K.cx) / K.fx;
+    bx1[p] = ((float)(kk / v.W) - K.cy) / K.fy;
   }
   const int pf = f - v.t0;
   // the self row exists for frames of the owned window (entry 0 of the slot) and feeds back
@@ -1650,7 +1657,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
 #pragma unroll
       for (int p = 0; p < BSUB_PPT; p++) {
         float eij[6];
-        e_row(K, T, sm.flag[x] != 0, kpix[p] < HW ? kpix[p] : 0, v.W, disp[p], wraw[p][0], wraw[p][1], eij);
+        e_row(K, T, sm.flag[x] != 0, bx0[p], bx1[p], disp[p], wraw[p][0], wraw[p][1], eij);
         float dw = 0.f;
 #pragma unroll
         for (int n = 0; n < 6; n++) dw += eij[n] * dxs[x][n];

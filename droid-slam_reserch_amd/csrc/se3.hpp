@@ -200,9 +200,9 @@ __device__ __forceinline__ PixLin linearize_pixel(const Intr& K, const Rel& T, f
 
 // Jacobians only (E rows of the Schur complement and of the back-substitution), fp32 matrix form:
 // 12 FMAs for the transform.  ru / rv are not set.
-__device__ __forceinline__ PixLin jacobians_pixel(const Intr& K, const float* R, const float* t, float u, float v,
+// X0, X1: the back-projected pixel ((u - cx) / fx, (v - cy) / fy), formed once per pixel by the caller
+__device__ __forceinline__ PixLin jacobians_pixel(const Intr& K, const float* R, const float* t, float X0, float X1,
                                                   float disp) {
-  const float X0 = (u - K.cx) / K.fx, X1 = (v - K.cy) / K.fy;
   const float x = R[0] * X0 + R[1] * X1 + R[2] + disp * t[0];
   const float y = R[3] * X0 + R[4] * X1 + R[5] + disp * t[1];
   const float z = R[6] * X0 + R[7] * X1 + R[8] + disp * t[2];
@@ -221,9 +221,10 @@ __device__ __forceinline__ PixLin jacobians_pixel(const Intr& K, const float* R,
 // 3e-5 of a typical 0.3 px residual, which the depth back-substitution dz = Q (w - E^T dx) hands through
 // to weakly observed pixels (measured: 1e-4 of a disparity that moves by 1.4 in two iterations).  The
 // Jacobians are formed in fp32 from the rounded point, like the reference's.
-__device__ __forceinline__ PixLin linearize_pixel_d(const Intr& K, const double* R, const double* t, float u, float v,
+// X0, X1: the back-projected pixel in fp64, ((double)u - cx) / fx etc., formed once per pixel by the caller (two fp64
+// divisions that would otherwise be repeated for every edge of the slot)
+__device__ __forceinline__ PixLin linearize_pixel_d(const Intr& K, const double* R, const double* t, double X0, double X1,
                                                     float disp, float tu, float tv) {
-  const double X0 = ((double)u - (double)K.cx) / (double)K.fx, X1 = ((double)v - (double)K.cy) / (double)K.fy;
   const double dd = (double)disp;
   const double x = R[0] * X0 + R[1] * X1 + R[2] + dd * t[0];
   const double y = R[3] * X0 + R[4] * X1 + R[5] + dd * t[1];
