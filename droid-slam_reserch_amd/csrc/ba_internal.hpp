@@ -37,7 +37,9 @@ __host__ __device__ inline size_t packed_offset(int i) {
   return 2 * m * (m + 1) + ((i & 1) ? 2 * m + 2 : 0);
 }
 
-enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4, HDR_WORDS = 16 };
+enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4,
+       HDR_NC1 = 5, HDR_NC2 = 6,  // slots served by the two SYRK variants (classes 1, 2)
+       HDR_WORDS = 16 };
 enum { STATUS_BAD_INDEX = 1, STATUS_ETA_ROWS = 2, STATUS_CHOL_FAIL = 4, STATUS_CHOL_STALL = 8 };
 
 // Plain-old-data view of the workspace, passed to kernels by value.
@@ -60,6 +62,7 @@ struct BaView {
   int* wk_ptr;             // [nbuf+1] scratch (slot sizes while sorting)
   int* order;              // [nbuf+1] slots sorted by descending edge count: big slots are dispatched first
   int* xtmp;               // [3(E+1)] prep scratch: unsorted segment fill, window flag and slot of every sorted position
+  int* cls_list;           // [2][nbuf+2] the slots of SYRK class 1 / class 2, ascending (ba_syrk_kernel)
   int* gt_ptr;             // [nbuf+2] first partial-sum tile of a slot served by ba_schur2_kernel (exclusive scan)
   double* Gpart;           // [tiles][s2_split][256] fp64 partial sums of those slots' Gram tiles, one per pixel range
   int s2_split;            // pixel ranges per slot of ba_schur2_kernel
@@ -112,6 +115,7 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.wk_ptr = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
   v.order = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
   v.gt_ptr = static_cast<int*>(take(sizeof(int) * (nbuf + 2)));
+  v.cls_list = static_cast<int*>(take(sizeof(int) * 2 * (nbuf + 2)));
   v.xtmp = static_cast<int*>(take(sizeof(int) * 3 * ((size_t)E + 1)));
   v.Hpart = static_cast<float*>(take(sizeof(float) * ((size_t)E * v.nch * 32 + 32)));
   v.Q = static_cast<float*>(take(sizeof(float) * ((size_t)M * v.HW + 4)));

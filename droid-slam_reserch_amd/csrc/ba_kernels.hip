@@ -136,6 +136,7 @@ constexpr int SF_RB = 96;             // rows per block (16 entries)
 // Dense slots (more than 16 entries) are served by the SYRK-only kernel further down.
 constexpr int SW_MID = 272;   // rows (incl. the w row) served by the two-workgroups-per-CU variant (45 entries)
 constexpr int SW_BIG = 512;   // rows served by the one-per-CU variant (85 entries)
+constexpr int SY_MAXSPLIT = 16;  // pixel ranges per slot of the SYRK kernels (each adds one fp64 atomic per output entry)
 
 // which kernel serves a slot: 0 = single 96-row block, 1/2 = SYRK-only kernel (E rows from v.Ebuf),
 // 3 = block pairs.
@@ -355,6 +356,27 @@ __global__ __launch_bounds__(1024) void ba_prep_kernel(BaView vg, const int64_t*
     v.order[rank] = m;
   }
   if (t == 0) v.hdr[HDR_NWORK] = 0;
+  // compact lists of the slots each SYRK variant serves (ascending slot index), so that ba_syrk_kernel can deal
+  // its workgroups over the slots that exist instead of leaving most of the grid to exit early
+  if (t < 2) v.hdr[HDR_NC1 + t] = 0;
+  __syncthreads();  // the rank loop above reads wk_ptr
+  for (int m = t; m < Ms; m += T) {
+    const int nent = v.ent_ptr[m + 1] - v.ent_ptr[m];
+    v.wk_ptr[m] = nent > 0 ? schur_class(6 * nent + 1, v.seg_ptr[m + 1] - v.seg_ptr[m], v.wide) : 0;
+  }
+  __syncthreads();
+  for (int m = t; m < Ms; m += T) {
+    const int c = v.wk_ptr[m];
+    if (c != 1 && c != 2) continue;
+    int pos = 0, after = 0;
+    for (int u = 0; u < Ms; u++) {
+      const int same = v.wk_ptr[u] == c;
+      pos += (same && u < m) ? 1 : 0;
+      after += (same && u > m) ? 1 : 0;
+    }
+    vg.cls_list[(c - 1) * (nbuf + 2) + pos] = m;
+    if (after == 0) v.hdr[HDR_NC1 + c - 1] = pos + 1;
+  }
   if (INLDS) {  // the tables the other kernels read
     __syncthreads();
     for (int f = t; f <= nbuf; f += T) {
@@ -1423,22 +1445,27 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
   constexpr int BUF_FLOATS = (ROWS + 8) * SY_TPX;       // + the Q row, rounded up to a DMA group of 8 rows
   constexpr int MAXSLOT = ((ROWS + 8) / 8 + NW - 1) / NW;  // DMA instructions per wave and stage
   __shared__ __attribute__((aligned(16))) float EB[2][BUF_FLOATS];
-  if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
-  const int m = v.order[blockIdx.x];
+  // workgroups (x, y) are dealt over the slots of this class (prep's compact list): w -> (slot w % count,
+  // pixel range w / count).  A class with few slots (two hub frames of an otherwise class-1 graph) gets up to
+  // SY_MAXSPLIT pixel ranges per slot instead of the launch-wide split chosen for `M` slots.
+  const int count = min(v.hdr[HDR_NC1 + CLS - 1], v.M);
+  if (count <= 0) return;
+  const int HW = v.HW;
+  const int stages_total = HW / SY_TPX;  // v.wide guarantees HW % 32 == 0
+  const int wgs = (int)(gridDim.x * gridDim.y), wlin = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+  const int nrange = max(1, min(min(wgs / count, SY_MAXSPLIT), stages_total));
+  if (wlin >= count * nrange) return;
+  const int m = v.cls_list[(CLS - 1) * (v.nbuf + 2) + wlin % count];
+  const int range = wlin / count;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int HW = v.HW;
   const int e0 = v.ent_ptr[m], nent = v.ent_ptr[m + 1] - e0;
-  if (nent == 0) return;
   const int R = 6 * nent;  // E rows; row R is the w row, row R+1 the Q row
-  const int nedges = v.seg_ptr[m + 1] - v.seg_ptr[m];
-  if (schur_class(R + 1, nedges, 1) != CLS) return;
   // pose index of every entry, for the fold (6 rows per entry; dependent global loads per folded element otherwise)
   __shared__ int s_pose[(ROWS + 5) / 6 + 1];
   for (int i = tid; i < nent; i += (int)blockDim.x) s_pose[i] = v.ent_pose[e0 + i];
-  const int stages_total = HW / SY_TPX;  // v.wide guarantees HW % 32 == 0
-  const int spw = (stages_total + gridDim.y - 1) / gridDim.y;
-  const int st_beg = blockIdx.y * spw, st_end = min(stages_total, st_beg + spw);
+  const int spw = (stages_total + nrange - 1) / nrange;
+  const int st_beg = range * spw, st_end = min(stages_total, st_beg + spw);
   if (st_beg >= st_end) return;
   const int ntr = (R + 1 + 15) / 16;              // 16-row tiles
   const int nst = (ntr + 1) / 2;                  // 32-row super-tile rows

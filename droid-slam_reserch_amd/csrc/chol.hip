@@ -253,7 +253,11 @@ __device__ __forceinline__ void potrf16_pivot(double (&a)[16], double (&w)[16], 
   for (int c = J + 1; c < 16; c++) {
     // unrolled with compile-time lane numbers
     switch (c) {
+#ifdef CHOL_NO_W  // timing experiment only (wrong inverses): the column operations on the identity rows left out
+#define DROID_CASE(CC) case CC: if (CC > J) { fmac_bcast<J, CC>(a[CC], a[J], a[J]); } break;
+#else
 #define DROID_CASE(CC) case CC: if (CC > J) { fmac_bcast<J, CC>(a[CC], a[J], a[J]); fmac_bcast<J, CC>(w[CC], a[J], w[J]); } break;
+#endif
       DROID_CASE(1) DROID_CASE(2) DROID_CASE(3) DROID_CASE(4) DROID_CASE(5) DROID_CASE(6) DROID_CASE(7) DROID_CASE(8)
       DROID_CASE(9) DROID_CASE(10) DROID_CASE(11) DROID_CASE(12) DROID_CASE(13) DROID_CASE(14) DROID_CASE(15)
 #undef DROID_CASE

@@ -36,3 +36,8 @@ t0 = bs[23, 0]
 print("back-substitution, per block column j: start, last x seen, mat-vec done, after sync, solved, published (us)")
 for j in range(23, -1, -1):
     print(f"j {j:2d}: " + " ".join(f"{(v - t0) / 100:7.2f}" for v in bs[j, :6]))
+print("phase deltas (us), mid columns: strips->loaded | last-strip updates | potrf0 | barrier | solve gemm (wave 0) | barrier wait | D11 update + potrf1 | barrier | p=1..3 | publish")
+for kp in (8, 12, 16):
+    for wg in (0, 1):
+        r = st[kp, wg].astype(float) / 100
+        print(f"col {kp:2d} wg {wg}: {r[1]-r[0]:6.2f} {r[2]-r[1]:6.2f} {r[3]-r[2]:6.2f} {r[4]-r[3]:6.2f} {r[10]-r[4]:6.2f} {r[5]-r[10]:6.2f} {r[6]-r[5]:6.2f} {r[7]-r[6]:6.2f} {r[8]-r[7]:6.2f} {r[13]-r[8]:6.2f}")

@@ -1,14 +1,18 @@
-"""Per-rank compute of the weak-scaling bench emulated on ONE GPU: for world = 1,2,4,8 build the
-2000*world-edge graph, take the shard of rank 0 and of the most loaded rank, and time the local
-iteration (no collective).  Shows how the per-rank stages move with the graph density."""
+"""Per-rank compute of the multi-GPU bench emulated on ONE GPU: for world = 1,2,4,8 build the graph, take the shard of
+rank 0 and of a middle rank, and time the local iteration (no collective).  Default: BASELINE configs[3], 8000 edges in
+total (what `bench.py --gpus N` runs); `weak`: 2000 edges per rank.  usage: scale_emul.py [weak]"""
 import sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/droid-slam_reserch_amd")
+WEAK = len(sys.argv) > 1 and sys.argv[1] == "weak"
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "droid-slam_reserch_amd")]
 import numpy as np, torch
 from droid_backends import ba_driver, synth
 dev = torch.device("cuda:0")
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 for world in (1, 2, 4, 8):
-    prob = synth.make_ba_problem(N=256, E=2000 * world, H=48, W=64, lm=1e-5, ep=1e-2, seed=synth.CONFIG_SEEDS["cfg3"])
+    prob = synth.make_ba_problem(N=256, E=(2000 * world if WEAK else 8000), H=48, W=64, lm=1e-5, ep=1e-2,
+                                 seed=synth.CONFIG_SEEDS["cfg3" if WEAK else "cfg4"])
     ranges = ba_driver.partition_frames(prob.ii, 256, world)
     for rank in sorted({0, world // 2}):
         sh = ba_driver.shard_problem(prob, ranges, rank)

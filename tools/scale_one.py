@@ -1,12 +1,14 @@
-"""One rank of the world-W weak-scaling bench on one GPU (for profiling): scale_one.py W [iterations]"""
+"""Rank 0 of the W-rank bench (BASELINE configs[3]: 8000 edges in total) on one GPU, for profiling: scale_one.py W [iterations]"""
 import sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/droid-slam_reserch_amd")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "droid-slam_reserch_amd")]
 import numpy as np, torch
 from droid_backends import ba_driver, synth
 world = int(sys.argv[1]); iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 dev = torch.device("cuda:0")
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-prob = synth.make_ba_problem(N=256, E=2000 * world, H=48, W=64, lm=1e-5, ep=1e-2, seed=synth.CONFIG_SEEDS["cfg3"])
+prob = synth.make_ba_problem(N=256, E=8000, H=48, W=64, lm=1e-5, ep=1e-2, seed=synth.CONFIG_SEEDS["cfg4"])  # BASELINE configs[3]
 ranges = ba_driver.partition_frames(prob.ii, 256, world)
 sh = ba_driver.shard_problem(prob, ranges, 0)
 p = ba_driver.BAProblemDev(poses=t(prob.poses), disps=t(prob.disps), intrinsics=t(prob.intrinsics), disps_sens=t(prob.disps_sens),
