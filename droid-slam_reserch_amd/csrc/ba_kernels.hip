@@ -1470,10 +1470,40 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
   const int ntr = (R + 1 + 15) / 16;              // 16-row tiles
   const int nst = (ntr + 1) / 2;                  // 32-row super-tile rows
   const int nsup_all = nst * (nst + 1) / 2;       // lower triangle of super-tiles
-  const int sshare = (nsup_all + NSHARE - 1) / NSHARE;
-  const int sup0 = (int)blockIdx.z * sshare;      // first super-tile of this workgroup
-  const int nsup = min(sshare, nsup_all - sup0);
+  // Super-tiles differ in cost: a diagonal one has no use for its strict upper tile (3 of 4 tiles), the last block row of
+  // an odd tile count has one tile row only (2 of 4; 1 in the corner).  They are sorted by cost and dealt out in that
+  // order -- position p to share p % NSHARE, there to the waves back and forth (0..7, 7..0, ..) -- so that shares, the
+  // four SIMDs and the waves all carry nearly the same number of MFMAs (13 row tiles: 91 useful tiles of 112).
+  __shared__ unsigned char s_cost[NST * (NST + 1) / 2];
+  __shared__ short s_sorted[NST * (NST + 1) / 2];
+  for (int i = tid; i < nsup_all; i += (int)blockDim.x) {
+    int sa, sb;
+    tri_coords(i, sa, sb);
+    const int rows2 = (2 * sa + 1 < ntr) ? 2 : 1;
+    s_cost[i] = (unsigned char)(sa == sb ? (rows2 == 2 ? 3 : 1) : 2 * rows2);
+  }
+  __syncthreads();
+  for (int i = tid; i < nsup_all; i += (int)blockDim.x) {
+    const int c = s_cost[i];
+    int pos = 0;
+    for (int o = 0; o < nsup_all; o++) {
+      const int co = s_cost[o];
+      pos += (co > c || (co == c && o < i)) ? 1 : 0;
+    }
+    if (pos % NSHARE == (int)blockIdx.z) s_sorted[pos / NSHARE] = (short)i;
+  }
+  __syncthreads();
+  const int nsup = (nsup_all - (int)blockIdx.z + NSHARE - 1) / NSHARE;  // super-tiles of this workgroup
   if (nsup <= 0) return;
+  // this wave's u-th super-tile: dealt position 8u + wave (u even) or 8u + 7 - wave (u odd)
+  int mysup[MAXS];
+  int nmine = 0;
+#pragma unroll
+  for (int u = 0; u < MAXS; u++) {
+    const int kpos = NW * u + ((u & 1) ? NW - 1 - wave : wave);
+    mysup[u] = __builtin_amdgcn_readfirstlane(kpos < nsup ? (int)s_sorted[kpos] : -1);
+    nmine += (mysup[u] >= 0) ? 1 : 0;
+  }
 
   // staging plan: DMA instruction k covers rows 8k..8k+7 (lane >> 3), 16-byte slot lane & 7 of each
   const int nrows = R + 2;
@@ -1510,18 +1540,18 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
   // LDS float offsets of this lane's operand rows per super-tile (constant over the stages); row + 16
   // keeps (row & 7), so the second tile row of a super-tile sits exactly 16 rows further.  A second
   // row block past the slot's tiles is folded onto the first (its results are never read).
-  int offa[MAXS], offb[MAXS], da[MAXS], db[MAXS];
+  int offa[MAXS], offb[MAXS];
+  bool upper[MAXS], second[MAXS];  // wave-uniform: the (a0, b1) tile is used / the second tile row exists
 #pragma unroll
   for (int u = 0; u < MAXS; u++) {
     int sa, sb;
-    tri_coords(min(sup0 + wave + NW * u, nsup_all - 1), sa, sb);
+    tri_coords(max(mysup[u], 0), sa, sb);
     const int ra = 32 * sa + r, rb = 32 * sb + r;
     offa[u] = ra * SY_TPX + 4 * (g ^ (ra & 7));
     offb[u] = rb * SY_TPX + 4 * (g ^ (rb & 7));
-    da[u] = (2 * sa + 1 < ntr) ? 16 * SY_TPX : 0;
-    db[u] = (2 * sb + 1 < ntr) ? 16 * SY_TPX : 0;
+    upper[u] = (sa != sb);                 // (an off-diagonal super-tile never sits in the last block column)
+    second[u] = (2 * sa + 1 < ntr);
   }
-  const int nmine = (max(nsup - wave, 0) + NW - 1) / NW;  // super-tiles of this wave
   const int qrow = R + 1;
   const int offq = qrow * SY_TPX + 4 * (g ^ (qrow & 7));
   issue_stage(st_beg, 0);
@@ -1538,21 +1568,43 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
     qv[1] = *reinterpret_cast<const f32x4*>(&Eb[offq ^ 16]);
 #pragma unroll
     for (int u = 0; u < MAXS; u++) {
-      if (u < nmine) {  // wave-uniform; four independent accumulation chains per super-tile
+      if (mysup[u] >= 0) {  // wave-uniform; up to four independent accumulation chains per super-tile
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           f32x4 a0 = *reinterpret_cast<const f32x4*>(&Eb[offa[u] ^ (16 * h)]);
-          f32x4 a1 = *reinterpret_cast<const f32x4*>(&Eb[(offa[u] + da[u]) ^ (16 * h)]);
           const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Eb[offb[u] ^ (16 * h)]);
-          const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Eb[(offb[u] + db[u]) ^ (16 * h)]);
           a0 = a0 * qv[h];
-          a1 = a1 * qv[h];
+          if (second[u]) {
+            f32x4 a1 = *reinterpret_cast<const f32x4*>(&Eb[(offa[u] + 16 * SY_TPX) ^ (16 * h)]);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Eb[(offb[u] + 16 * SY_TPX) ^ (16 * h)]);
+            a1 = a1 * qv[h];
+            asm volatile("" : "+v"(a0), "+v"(a1));  // all products first (the compiler recycles one register otherwise)
+            if (upper[u]) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc[u][0], 0, 0, 0);
-            acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b1[e], acc[u][1], 0, 0, 0);
-            acc[u][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b0[e], acc[u][2], 0, 0, 0);
-            acc[u][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc[u][3], 0, 0, 0);
+              for (int e = 0; e < 4; e++) {
+                acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc[u][0], 0, 0, 0);
+                acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b1[e], acc[u][1], 0, 0, 0);
+                acc[u][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b0[e], acc[u][2], 0, 0, 0);
+                acc[u][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc[u][3], 0, 0, 0);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc[u][0], 0, 0, 0);
+                acc[u][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b0[e], acc[u][2], 0, 0, 0);
+                acc[u][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc[u][3], 0, 0, 0);
+              }
+            }
+          } else if (upper[u]) {  // last block row of an odd tile count: one tile row against two tile columns
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Eb[(offb[u] + 16 * SY_TPX) ^ (16 * h)]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc[u][0], 0, 0, 0);
+              acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b1[e], acc[u][1], 0, 0, 0);
+            }
+          } else {  // its corner
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc[u][0], 0, 0, 0);
           }
         }
       }
@@ -1561,9 +1613,9 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
   // ---- fold the accumulators into the dense system (A - S): lower triangle, fp64 atomics
 #pragma unroll
   for (int u = 0; u < MAXS; u++) {
-    if (u < nmine) {
+    if (mysup[u] >= 0) {
       int sa, sb;
-      tri_coords(sup0 + wave + NW * u, sa, sb);
+      tri_coords(mysup[u], sa, sb);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int ta = 2 * sa + (q >> 1), tb = 2 * sb + (q & 1);

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cmath>
 #include <vector>
+#include "potrf16_asm.inc"
 __device__ __forceinline__ double rsqrt_h(double d) {
   double y = __builtin_amdgcn_rsq(d);
   const double e = fma(-d * y, y, 1.0);
@@ -121,6 +122,18 @@ __global__ void k(const double* A, double* L, double* W, unsigned long long* cyc
 #pragma unroll
     for (int c = 0; c < 16; c++) { a[c] = Lb[row * 18 + c]; w[c] = Idn[row * 16 + c]; }
     double ylast = 0;
+    if (V == 5) {   // the generated single-block form (tools/gen_potrf16_asm.py)
+      if (lane < 16) {
+        const unsigned pa = (unsigned)(size_t)((__attribute__((address_space(3))) double*)&Lb[row * 18]);
+        const unsigned pi = (unsigned)(size_t)((__attribute__((address_space(3))) double*)&Idn[row * 16]);
+        const unsigned pw = (unsigned)(size_t)((__attribute__((address_space(3))) double*)&Wl[row]);
+        double yl;
+        asm volatile(DROID_POTRF16_ASM : "=&v"(yl) : "v"(pa), "v"(pi), "v"(pw) : DROID_POTRF16_CLOBBERS);
+        asm volatile("" :: "v"(yl));
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      continue;
+    }
     if (V == 4) {
       double d0, y;
       asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(d0) : "v"(a[0]));
@@ -167,6 +180,8 @@ void run(const double* dA, const std::vector<double>& A, int threads) {
     double t = 0; for (int kk = j; kk <= i; kk++) t += W[i * 16 + kk] * L[kk * 16 + j];
     e2m = fmax(e2m, fabs(t - (i == j ? 1.0 : 0.0)));
   }
+  double cs = 0; for (int i = 0; i < 16; i++) for (int j = 0; j <= i; j++) cs += L[i * 16 + j] * (1 + i + 17 * j) + W[i * 16 + j] * (3 + j + 13 * i);
+  printf("checksum %.17g  ", cs);
   printf("variant %d (%d threads): %.3f us per block (events), %.1f s_memtime ticks per block | |LL^T-A| %.2e |L^-1 L - I| %.2e\n",
          V, threads, ms * 1e3 / reps, (double)cyc / (reps - 1), e1m, e2m);
 }
@@ -175,6 +190,6 @@ int main() {
   for (int i = 0; i < 256; i++) B[i] = sin(0.37 * i) + ((i % 17) == 0 ? 3.0 : 0.0);
   for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) { double s = (i == j) ? 4.0 : 0.0; for (int kk = 0; kk < 16; kk++) s += B[i * 16 + kk] * B[j * 16 + kk]; A[i * 16 + j] = s; }
   double* dA; (void)hipMalloc(&dA, 2048); (void)hipMemcpy(dA, A.data(), 2048, hipMemcpyHostToDevice);
-  for (int threads : {64, 512}) { run<0>(dA, A, threads); run<1>(dA, A, threads); run<2>(dA, A, threads); run<3>(dA, A, threads); run<4>(dA, A, threads); }
+  for (int threads : {64, 512}) { run<0>(dA, A, threads); run<1>(dA, A, threads); run<2>(dA, A, threads); run<3>(dA, A, threads); run<4>(dA, A, threads); run<5>(dA, A, threads); }
   return 0;
 }
