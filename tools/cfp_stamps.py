@@ -3,7 +3,8 @@ Build: -DCHOL_STAMPS into tools/libs/lib_stamps.so (tools/README.md)."""
 import sys, ctypes
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/droid-slam_reserch_amd")
 import numpy as np, torch
-lib = ctypes.CDLL("/root/repo/tools/libs/lib_stamps.so")
+import os
+lib = ctypes.CDLL(os.environ.get("STAMPS_LIB", "/root/repo/tools/libs/lib_stamps.so"))
 lib.droid_chol_scratch_doubles.argtypes = [ctypes.c_int]
 lib.droid_chol_scratch_doubles.restype = ctypes.c_size_t
 n = 1530

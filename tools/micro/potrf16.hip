@@ -106,13 +106,15 @@ __device__ __forceinline__ void pivot_sp(double (&a)[16], double (&w)[16], doubl
   upd<J, 23>(a, w); upd<J, 24>(a, w); upd<J, 25>(a, w); upd<J, 26>(a, w); upd<J, 27>(a, w); upd<J, 28>(a, w); upd<J, 29>(a, w);
 }
 template <int V>
-__global__ void k(const double* A, double* L, double* W, unsigned long long* cyc, int reps) {
-  __shared__ double Lb[16 * 18], Idn[256], Wl[256], Asrc[256];
+__global__ void k(const double* A, double* L, double* W, unsigned long long* cyc, int reps, int nactive = 1) {
+  __shared__ double LbAll[8][16 * 18], Idn[256], WlAll[8][256], Asrc[256];
+  double* Lb = LbAll[threadIdx.x >> 6];
+  double* Wl = WlAll[threadIdx.x >> 6];
   for (int i = threadIdx.x; i < 256; i += blockDim.x) Asrc[i] = A[i];
   const int lane = threadIdx.x & 63, row = lane & 15;
   for (int i = threadIdx.x; i < 256; i += blockDim.x) Idn[i] = ((i >> 4) == (i & 15)) ? 1.0 : 0.0;
   __syncthreads();
-  if (threadIdx.x >= 64) return;
+  if ((int)threadIdx.x >= 64 * nactive) return;
   unsigned long long t0 = 0, t1 = 0;
   for (int r = 0; r < reps; r++) {
     for (int c = lane; c < 256; c += 64) Lb[(c >> 4) * 18 + (c & 15)] = Asrc[c];
@@ -155,18 +157,18 @@ __global__ void k(const double* A, double* L, double* W, unsigned long long* cyc
     __builtin_amdgcn_s_waitcnt(0);
   }
   t1 = __builtin_amdgcn_s_memtime();
-  for (int c = lane; c < 256; c += 64) { L[c] = Lb[(c >> 4) * 18 + (c & 15)]; W[c] = Wl[c]; }
-  if (lane == 0) cyc[0] = t1 - t0;
+  if (threadIdx.x < 64) for (int c = lane; c < 256; c += 64) { L[c] = Lb[(c >> 4) * 18 + (c & 15)]; W[c] = Wl[c]; }
+  if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 template <int V>
-void run(const double* dA, const std::vector<double>& A, int threads) {
+void run(const double* dA, const std::vector<double>& A, int threads, int nactive = 1) {
   double *dL, *dW; unsigned long long* dc;
   (void)hipMalloc(&dL, 2048); (void)hipMalloc(&dW, 2048); (void)hipMalloc(&dc, 64);
   const int reps = 2001;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  k<V><<<1, threads>>>(dA, dL, dW, dc, reps);
+  k<V><<<1, threads>>>(dA, dL, dW, dc, reps, nactive);
   (void)hipEventRecord(e0);
-  k<V><<<1, threads>>>(dA, dL, dW, dc, reps);
+  k<V><<<1, threads>>>(dA, dL, dW, dc, reps, nactive);
   (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   std::vector<double> L(256), W(256); unsigned long long cyc;
@@ -182,6 +184,7 @@ void run(const double* dA, const std::vector<double>& A, int threads) {
   }
   double cs = 0; for (int i = 0; i < 16; i++) for (int j = 0; j <= i; j++) cs += L[i * 16 + j] * (1 + i + 17 * j) + W[i * 16 + j] * (3 + j + 13 * i);
   printf("checksum %.17g  ", cs);
+  printf("[%d active waves] ", nactive);
   printf("variant %d (%d threads): %.3f us per block (events), %.1f s_memtime ticks per block | |LL^T-A| %.2e |L^-1 L - I| %.2e\n",
          V, threads, ms * 1e3 / reps, (double)cyc / (reps - 1), e1m, e2m);
 }
@@ -191,5 +194,6 @@ int main() {
   for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) { double s = (i == j) ? 4.0 : 0.0; for (int kk = 0; kk < 16; kk++) s += B[i * 16 + kk] * B[j * 16 + kk]; A[i * 16 + j] = s; }
   double* dA; (void)hipMalloc(&dA, 2048); (void)hipMemcpy(dA, A.data(), 2048, hipMemcpyHostToDevice);
   for (int threads : {64, 512}) { run<0>(dA, A, threads); run<1>(dA, A, threads); run<2>(dA, A, threads); run<3>(dA, A, threads); run<4>(dA, A, threads); run<5>(dA, A, threads); }
+  for (int na : {1, 2, 3, 4, 5, 8}) run<0>(dA, A, 512, na);
   return 0;
 }
