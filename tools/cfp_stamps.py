@@ -22,7 +22,7 @@ for _ in range(3):
 print("err", np.abs(x.cpu().numpy() - np.linalg.solve(A, b)).max())
 buf = (ctypes.c_ulonglong * (64 * 16))()
 lib.droid_debug_chol_stamps(buf)
-st = np.array(buf[:], dtype=np.int64).reshape(32, 2, 16)
+st = np.array(buf[:], dtype=np.uint64).astype(np.int64).reshape(32, 2, 16)
 t0 = st[0, 0, 11]
 print("columns: wait-begin, inputs-seen, body-start(0), loaded(1), upd(2), potrf0(3), bar(4), trsm0(5), potrf1(6), (7), p123(8), stored(9), published(13); us since start")
 for kp in range(0, 24):
@@ -42,3 +42,8 @@ for kp in (8, 12, 16):
     for wg in (0, 1):
         r = st[kp, wg].astype(float) / 100
         print(f"col {kp:2d} wg {wg}: {r[1]-r[0]:6.2f} {r[2]-r[1]:6.2f} {r[3]-r[2]:6.2f} {r[4]-r[3]:6.2f} {r[10]-r[4]:6.2f} {r[5]-r[10]:6.2f} {r[6]-r[5]:6.2f} {r[7]-r[6]:6.2f} {r[8]-r[7]:6.2f} {r[13]-r[8]:6.2f}")
+print("inside wave 0's first solve GEMM (diagnostic build only): barrier -> operands loaded | 4 MFMAs | stores + return")
+for kp in (8, 12, 16):
+    for wg in (0, 1):
+        r = st[kp, wg].astype(float) / 100
+        print(f"col {kp:2d} wg {wg}: {r[14]-r[4]:6.2f} {r[15]-r[14]:6.2f} {r[10]-r[15]:6.2f}")

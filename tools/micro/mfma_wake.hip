@@ -23,6 +23,18 @@ __global__ void k(double* out, unsigned long long* cyc, int nvalu, int mode) {
       for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
       asm volatile("" : "+v"(acc));
       x += acc[0] * 1e-300;
+    } else if (mode == 2) {   // the same product with FLAT (generic-pointer) accesses to LDS, as chol.hip's wave_gemm_nt16
+      double* Tf = (double*)T;
+      asm volatile("" : "+v"(Tf));
+      f64x4 a2 = {0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 4) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tf[r * 66 + kk + g], Tf[16 * 66 + r * 66 + kk + g], a2, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; i++) Tf[(g + 4 * i) * 66 + r + 32] -= a2[i];
+      __builtin_amdgcn_s_waitcnt(0);
+    } else if (mode == 3) {   // one global load (L2 hit)
+      x += out[64 + lane];
+      asm volatile("" : "+v"(x));
     } else {
       f64x4 a2 = {0, 0, 0, 0};
 #pragma unroll
@@ -40,12 +52,12 @@ __global__ void k(double* out, unsigned long long* cyc, int nvalu, int mode) {
 int main() {
   double* d; unsigned long long* c;
   (void)hipMalloc(&d, 512 * 8); (void)hipMalloc(&c, 64);
-  for (int mode = 0; mode < 2; mode++)
+  for (int mode = 0; mode < 4; mode++)
     for (int n : {0, 16, 64, 256, 1024, 4096}) {
       k<<<1, 64>>>(d, c, n, mode); k<<<1, 64>>>(d, c, n, mode);
       (void)hipDeviceSynchronize();
       unsigned long long h; (void)hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
-      printf("%s after %5d dependent v_fma_f64 (~%6d cycles idle matrix pipe): %llu ticks\n", mode ? "LDS gemm 16x16x16 (loads, 4 MFMA, RMW store)" : "4 dependent f64 MFMAs", n, n * 8, h);
+      printf("%s after %5d dependent v_fma_f64 (~%6d cycles idle matrix pipe): %llu ticks\n", mode == 0 ? "4 dependent f64 MFMAs" : mode == 1 ? "LDS gemm 16x16x16 (ds loads, 4 MFMA, RMW store)" : mode == 2 ? "same product with FLAT accesses to LDS" : "one global load (L2 hit)", n, n * 8, h);
     }
   return 0;
 }
