@@ -38,13 +38,19 @@ constexpr int NB = CHOL_NB;
 // Single-launch kernel: wall-clock (100 MHz, chip-wide) stamps of the diagonal workgroup and the one below it;
 // slots 11..13 = {wait begins, inputs seen, tile published}.
 __device__ unsigned long long g_chol_stamps[64 * 16];
+__shared__ unsigned long long g_chol_lstamps[16];  // slots 14, 15: inside wave 0's first solve GEMM (operands loaded, MFMAs done)
 #define STAMP(slot)                                                                         \
   do {                                                                                      \
     if (!PERSIST && threadIdx.x == 0 && panel && (blockIdx.x < 2)) {                                     \
       g_chol_stamps[((k + 1) & 31) * 32 + blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
     }                                                                                       \
     if (PERSIST && threadIdx.x == 0 && panel && (bi - kp < 2)) {                              \
-      g_chol_stamps[((k + 1) & 31) * 32 + (bi - kp) * 16 + (slot)] = wall_clock64();          \
+      /* into LDS (a global store here would sit in front of the next s_waitcnt vmcnt(0)); flushed at slot 8 */ \
+      g_chol_lstamps[slot] = wall_clock64();                                                  \
+      if ((slot) == 2) { g_chol_lstamps[14] = 0; g_chol_lstamps[15] = 0; }                    \
+      if ((slot) == 8)                                                                        \
+        for (int ss = 0; ss < 16; ss++)                                                       \
+          if (ss < 11 || ss > 13) g_chol_stamps[((k + 1) & 31) * 32 + (bi - kp) * 16 + ss] = g_chol_lstamps[ss]; \
     }                                                                                       \
   } while (0)
 #define PSTAMP(slot)                                                                        \
@@ -205,9 +211,21 @@ __device__ __attribute__((noinline)) void wave_gemm_nt16(lds_f64* Cl, const lds_
   const double* B = (const double*)Bl;
   asm volatile("" : "+v"(C), "+v"(A), "+v"(B));
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#ifdef CHOL_STAMPS
+  double av[4], bv[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { av[k] = A[r * LDP + 4 * k + g]; bv[k] = B[r * ldb + 4 * k + g]; }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (ASSIGN && threadIdx.x == 0 && g_chol_lstamps[14] == 0) g_chol_lstamps[14] = wall_clock64();
+#pragma unroll
+  for (int k = 0; k < 4; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], bv[k], acc, 0, 0, 0);
+  asm volatile("s_nop 15\n s_nop 15" : "+v"(acc));
+  if (ASSIGN && threadIdx.x == 0 && g_chol_lstamps[15] == 0) g_chol_lstamps[15] = wall_clock64();
+#else
 #pragma unroll
   for (int k = 0; k < 16; k += 4)
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[r * LDP + k + g], B[r * ldb + k + g], acc, 0, 0, 0);
+#endif
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     double* c = &C[(g + 4 * i) * LDP + r];
