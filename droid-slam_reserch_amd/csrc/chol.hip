@@ -62,6 +62,8 @@ __shared__ unsigned long long g_chol_lstamps[16];  // slots 14, 15: inside wave 
 #define PSTAMP(slot) do { } while (0)
 #endif
 constexpr int LDP = NB + 2;  // LDS row pitch in doubles: rows stay 16-B aligned, b64 MFMA operand reads conflict-free
+constexpr int WLP = 18;   // row pitch of an inverse block: with 16 the 16 rows of a GEMM operand read fell on two banks
+constexpr int WLB = 16 * WLP;  // doubles per inverse block
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -238,7 +240,7 @@ __device__ __attribute__((noinline)) void wave_gemm_nt16(lds_f64* Cl, const lds_
 // of column operations (scale column j, subtract multiples of it from the later columns) whose
 // scalars travel by v_readlane; applied to the identity rows as well they leave L^-T there, so
 // the inverse comes for free and every triangular solve against this block becomes a GEMM.
-// Outputs: L (lower part, in place) and Wl[j*16 + k] = (L^-1)[j][k].
+// Outputs: L (lower part, in place) and Wl[j*WLP + k] = (L^-1)[j][k].
 // The wave runs alone on its SIMD and issues ~one instruction per 4-6 cycles whatever the type, so
 // the instruction COUNT is the cost (measured: 3.1-3.5 cycles per removed instruction).  Hence:
 //   * lane r (0..15) keeps row r of the block AND row r of the identity (32 doubles), so that all
@@ -291,7 +293,7 @@ __device__ __forceinline__ void wave_potrf16(lds_f64* Lb, lds_f64* Wl, const lds
 #pragma unroll
   for (int c = 0; c < 16; c++) {
     a[c] = Lb[row * LDP + c];
-    w[c] = Idn[row * 16 + c];
+    w[c] = Idn[row * WLP + c];
   }
   double ylast = 0.0;
   potrf16_pivot<0>(a, w, ylast);   potrf16_pivot<1>(a, w, ylast);   potrf16_pivot<2>(a, w, ylast);
@@ -304,7 +306,7 @@ __device__ __forceinline__ void wave_potrf16(lds_f64* Lb, lds_f64* Wl, const lds
 #pragma unroll
     for (int c = 0; c < 16; c++) {
       Lb[row * LDP + c] = a[c];
-      Wl[c * 16 + row] = w[c];
+      Wl[c * WLP + row] = w[c];
     }
   }
   const bool bad = !(ylast > 0.0 && ylast < 1.0e300);  // NaN (non-positive pivot somewhere) or overflow
@@ -462,8 +464,8 @@ __shared__ double g_cholB0[NB * LDP];
 __shared__ double g_cholB1[NB * LDP];
 __shared__ double g_cholB2[NB * LDP];
 __shared__ double g_cholBT[NB * LDP];
-__shared__ double g_cholWl[4 * 256];
-__shared__ double g_cholIdn[256];
+__shared__ double g_cholWl[4 * WLB];
+__shared__ double g_cholIdn[WLB];  // (same padded pitch)
 
 // The body is shared by the one-launch-per-step kernel and the single-launch kernel below
 // (PERSIST: the workgroup is handed tile (bi, bj) of step k by its caller, the factored diagonal
@@ -544,7 +546,7 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
   // rows to solve: the own tile, or for the diagonal workgroup the rows of its block below the
   // diagonal tile (only the rhs row, and only when the last block column is narrower than NB)
   const bool solve_rows = !diag || (wk < NB);
-  if (t < 256) Idn[t] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;  // visible after the barrier below
+  if (t < 256) Idn[(t >> 4) * WLP + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;  // visible after the barrier below
   STAMP(0);
   // 16x16 tiles (rg, nt): D = diagonal tile (lower part), T = the tile to solve.  Only what the
   // first pivot block and the first solve need is updated up front (all of D, column 0 of T);
@@ -676,10 +678,10 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
       const int nd = 3 - p;  // diagonal-tile blocks below the pivot block
       if (wave < nd) {
         const int q = p + 1 + wave;
-        wave_gemm_nt16<true>(&B2[(16 * q) * LDP + 16 * p], &B2[(16 * q) * LDP + 16 * p], &Wl[256 * p], 16);
+        wave_gemm_nt16<true>(&B2[(16 * q) * LDP + 16 * p], &B2[(16 * q) * LDP + 16 * p], &Wl[WLB * p], WLP);
       } else if (solve_rows && wave < nd + 4) {
         const int g = wave - nd;
-        wave_gemm_nt16<true>(&BT[(16 * g) * LDP + 16 * p], &BT[(16 * g) * LDP + 16 * p], &Wl[256 * p], 16);
+        wave_gemm_nt16<true>(&BT[(16 * g) * LDP + 16 * p], &BT[(16 * g) * LDP + 16 * p], &Wl[WLB * p], WLP);
       }
     }
     if (p == 0) STAMP(10);
@@ -722,7 +724,7 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
     if (wave == 0) {  // the pivot chain: next diagonal block, then its factorisation
       wave_gemm_nt16<false>(&B2[(16 * q) * LDP + 16 * q], &B2[(16 * q) * LDP + 16 * p],
                             &B2[(16 * q) * LDP + 16 * p], LDP);
-      wave_potrf16(&B2[(16 * q) * LDP + 16 * q], &Wl[256 * q], Idn, fail, diag);
+      wave_potrf16(&B2[(16 * q) * LDP + 16 * q], &Wl[WLB * q], Idn, fail, diag);
       if (p == 0) STAMP(6);
     } else {
       // the other rank-16 updates of the diagonal tile, round-robin over the less loaded waves (not wave 4: it
@@ -785,7 +787,7 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
         f64x4 m = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 4)  // M_q = acc * L_qq^-1
-          m = __builtin_amdgcn_mfma_f64_16x16x4f64(Cq[fr * LDP + kk + fg], Wl[256 * q + (kk + fg) * 16 + fr], m, 0, 0, 0);
+          m = __builtin_amdgcn_mfma_f64_16x16x4f64(Cq[fr * LDP + kk + fg], Wl[WLB * q + (kk + fg) * WLP + fr], m, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; i++) Cq[(fg + 4 * i) * LDP + fr] = m[i];
       }
@@ -808,7 +810,7 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
     for (int e = t; e < 1024; e += 512) {
       const int pb = e >> 8, j = (e >> 4) & 15, kk = e & 15;
       const int br = pb == 3 ? 1 : 0, bc = pb == 3 ? 2 : pb + 1;
-      B2[(16 * br + j) * LDP + 16 * bc + kk] = Wl[e];
+      B2[(16 * br + j) * LDP + 16 * bc + kk] = Wl[WLB * pb + WLP * j + kk];
     }
     __syncthreads();
   }
