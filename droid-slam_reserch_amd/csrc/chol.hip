@@ -47,7 +47,7 @@ __shared__ unsigned long long g_chol_lstamps[16];  // slots 14, 15: inside wave 
     if (PERSIST && threadIdx.x == 0 && panel && (bi - kp < 2)) {                              \
       /* into LDS (a global store here would sit in front of the next s_waitcnt vmcnt(0)); flushed at slot 8 */ \
       g_chol_lstamps[slot] = wall_clock64();                                                  \
-      if ((slot) == 2) { g_chol_lstamps[14] = 0; g_chol_lstamps[15] = 0; }                    \
+      if ((slot) == 2) { g_chol_lstamps[14] = 0; g_chol_lstamps[15] = 0; g_chol_lstamps[9] = 0; }                    \
       if ((slot) == 8)                                                                        \
         for (int ss = 0; ss < 16; ss++)                                                       \
           if (ss < 11 || ss > 13) g_chol_stamps[((k + 1) & 31) * 32 + (bi - kp) * 16 + ss] = g_chol_lstamps[ss]; \
@@ -196,6 +196,13 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return y;
 }
 
+// MFMA operand fetch from an LDS tile of pitch LDP.  `volatile` on purpose: left alone the compiler fuses neighbouring
+// 8-byte reads into ds_read2_b64, which the LDS services in 16-lane groups with banks taken mod 32 -- 8 LDS cycles per
+// instruction and, with 16-byte aligned rows, always a 2-way conflict -- where two plain ds_read_b64 (32-lane groups,
+// 64 banks, conflict-free at pitch 66) take 4 cycles.  PMC on the factorisation before the change: 172 ds_read2_b64
+// sites, SQ_LDS_BANK_CONFLICT = 42 % of SQ_LDS_IDX_ACTIVE, LDS busy ~70 % of a panel workgroup's time.
+__device__ __forceinline__ double lds_operand(const lds_f64* p) { return *(const volatile lds_f64*)p; }
+
 // C(16x16) -= A(16x16) * B(16x16)^T on one wave.  A, C: LDS blocks with row pitch LDP; B: LDS
 // block with row pitch ldb.  v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4], B^T[l>>4][l&15];
 // result register i of lane l is D[(l>>4) + 4i][l&15].
@@ -203,36 +210,50 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // twice per workgroup; inlined, every call site is cold code and the instruction-cache misses cost
 // 4-5x the arithmetic (measured with s_memtime: 2.3-3.1k cycles cold vs 0.5k warm per call).
 template <bool ASSIGN>
-__device__ __attribute__((noinline)) void wave_gemm_nt16(lds_f64* Cl, const lds_f64* Al, const lds_f64* Bl, int ldb) {
+__device__ __forceinline__ void wave_gemm_nt16_inl(lds_f64* Cl, const lds_f64* Al, const lds_f64* Bl, int ldb) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  // The operands are read with FLAT loads on purpose: measured on the pivot chain, the ds_read form of this
-  // function (whatever the order of reads and MFMAs) costs 1.3 us more per block column than eight flat loads
-  // issued back to back.  The pointers are laundered so that address-space inference does not turn them back.
+#ifdef CHOL_GEMM_FLAT
+  // (round 1 read the operands with FLAT loads: its ds_read form was 1.3 us slower per block column -- because the compiler
+  // had fused the reads into conflicting ds_read2_b64, see lds_operand() -- kept for A/B builds)
   double* C = (double*)Cl;
   const double* A = (const double*)Al;
   const double* B = (const double*)Bl;
   asm volatile("" : "+v"(C), "+v"(A), "+v"(B));
-  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#ifdef CHOL_STAMPS
-  double av[4], bv[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) { av[k] = A[r * LDP + 4 * k + g]; bv[k] = B[r * ldb + 4 * k + g]; }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  if (ASSIGN && threadIdx.x == 0 && g_chol_lstamps[14] == 0) g_chol_lstamps[14] = wall_clock64();
-#pragma unroll
-  for (int k = 0; k < 4; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], bv[k], acc, 0, 0, 0);
-  asm volatile("s_nop 15\n s_nop 15" : "+v"(acc));
-  if (ASSIGN && threadIdx.x == 0 && g_chol_lstamps[15] == 0) g_chol_lstamps[15] = wall_clock64();
+#define DROID_GEMM_LD(p) (*(p))
 #else
-#pragma unroll
-  for (int k = 0; k < 16; k += 4)
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[r * LDP + k + g], B[r * ldb + k + g], acc, 0, 0, 0);
+  lds_f64* C = Cl;
+  const lds_f64* A = Al;
+  const lds_f64* B = Bl;
+#define DROID_GEMM_LD(p) lds_operand(p)
+#endif
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  double av[4], bv[4], cv[4];
+#ifdef CHOL_STAMPS
+  if (ASSIGN && threadIdx.x == 0 && g_chol_lstamps[9] == 0) g_chol_lstamps[9] = wall_clock64();   // function entered
 #endif
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    double* c = &C[(g + 4 * i) * LDP + r];
-    *c = ASSIGN ? acc[i] : *c - acc[i];
+  for (int k = 0; k < 4; k++) { av[k] = DROID_GEMM_LD(&A[r * LDP + 4 * k + g]); bv[k] = DROID_GEMM_LD(&B[r * ldb + 4 * k + g]); }
+  if (!ASSIGN) {  // the block to update travels with the operands instead of after the products
+#pragma unroll
+    for (int i = 0; i < 4; i++) cv[i] = DROID_GEMM_LD(&C[(g + 4 * i) * LDP + r]);
   }
+#ifdef CHOL_STAMPS
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (ASSIGN && threadIdx.x == 0 && g_chol_lstamps[14] == 0) g_chol_lstamps[14] = wall_clock64();
+#endif
+#pragma unroll
+  for (int k = 0; k < 4; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], bv[k], acc, 0, 0, 0);
+#ifdef CHOL_STAMPS
+  asm volatile("s_nop 15\n s_nop 15" : "+v"(acc));
+  if (ASSIGN && threadIdx.x == 0 && g_chol_lstamps[15] == 0) g_chol_lstamps[15] = wall_clock64();
+#endif
+#pragma unroll
+  for (int i = 0; i < 4; i++) C[(g + 4 * i) * LDP + r] = ASSIGN ? acc[i] : cv[i] - acc[i];
+#undef DROID_GEMM_LD
+}
+template <bool ASSIGN>
+__device__ __attribute__((noinline)) void wave_gemm_nt16(lds_f64* Cl, const lds_f64* Al, const lds_f64* Bl, int ldb) {
+  wave_gemm_nt16_inl<ASSIGN>(Cl, Al, Bl, ldb);
 }
 
 // In-register Cholesky of the 16x16 block at Lb (LDS, pitch LDP) by one wave.  Lane l < 16 holds
@@ -314,6 +335,7 @@ __device__ __forceinline__ void wave_potrf16(lds_f64* Lb, lds_f64* Wl, const lds
   __builtin_amdgcn_s_setprio(0);
 }
 
+
 // 16-row strip of a 64x64 tile update: acc[0..NN) (row group rg, column tiles nt0..nt0+NN) -= Lr Lc^T.
 template <int NN>
 __device__ __forceinline__ void strip_update(f64x4 (&acc)[4], const lds_f64* Lr, const lds_f64* Lc, int rg,
@@ -323,10 +345,10 @@ __device__ __forceinline__ void strip_update(f64x4 (&acc)[4], const lds_f64* Lr,
   const lds_f64* Ar = &Lr[(16 * rg + r) * LDP + g];
 #pragma unroll 4
   for (int kk = 0; kk < NB; kk += 4) {
-    const double a = -Ar[kk];
+    const double a = -lds_operand(&Ar[kk]);
 #pragma unroll
     for (int nn = 0; nn < NN; nn++)
-      acc[nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lc[(16 * (nt0 + nn) + r) * LDP + kk + g], acc[nn], 0, 0, 0);
+      acc[nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lds_operand(&Lc[(16 * (nt0 + nn) + r) * LDP + kk + g]), acc[nn], 0, 0, 0);
   }
 }
 
@@ -358,7 +380,7 @@ __device__ __forceinline__ void strip_update_tile(f64x4& acc, const lds_f64* Lr,
   // fully unrolled: all 32 operand reads of the tile are in flight before the first MFMA, so the
   // LDS latency is paid once per tile and the 16 MFMAs issue back to back
 #pragma unroll
-  for (int kk = 0; kk < NB; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ar[kk], Br[kk], acc, 0, 0, 0);
+  for (int kk = 0; kk < NB; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lds_operand(&Ar[kk]), lds_operand(&Br[kk]), acc, 0, 0, 0);
 }
 template <bool COH = false>
 __device__ __forceinline__ void frag_load_tile(f64x4& acc, const gbl_f64* __restrict__ S, int ld, int r0, int q0,
@@ -380,7 +402,7 @@ __device__ __forceinline__ void block_update16(f64x4& acc, const lds_f64* A, con
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int kk = 0; kk < 16; kk += 4)
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[r * LDP + kk + g], B[r * LDP + kk + g], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lds_operand(&A[r * LDP + kk + g]), lds_operand(&B[r * LDP + kk + g]), acc, 0, 0, 0);
 }
 
 // One step of the blocked right-looking factorisation in ONE launch of 512-thread workgroups:
@@ -470,6 +492,57 @@ __shared__ double g_cholIdn[WLB];  // (same padded pitch)
 // The body is shared by the one-launch-per-step kernel and the single-launch kernel below
 // (PERSIST: the workgroup is handed tile (bi, bj) of step k by its caller, the factored diagonal
 // tile goes to the side buffer Ldiag instead of overwriting the tile other workgroups still read).
+// Columns 16p..16p+15 of the solved tile (LDS, BT) are final: one wave writes them through and publishes the strip; the next
+// block column's workgroups start their rank-16 updates on it right away.  Scalar base + 32-bit lane offsets: with
+// per-lane 64-bit addresses and row predicates per store, ~200 loop-invariant instructions of this block were hoisted in
+// front of the 16-column loop of the panel path, i.e. behind the first pivot block on EVERY wave including the pivot
+// chain (0.25 us per block column, stamps).  Inlined on purpose: a function of its own has to wait for its write-through
+// stores before it returns, which puts their round trip in front of the next barrier (+0.4 us, stamps).
+__device__ __forceinline__ void chol_strip_out(gbl_f64* __restrict__ S, int ld, gbl_f64* __restrict__ slot,
+                                                         const lds_f64* __restrict__ BT, int r0, int c0, int wk, int nrows,
+                                                         int p, int* done_flag, int done_value) {
+  const int lane = threadIdx.x & 63;
+  const int rb = max(r0, c0 + wk) - r0, re = min(r0 + NB, nrows) - r0;   // tile-local row range to publish
+  const int i0 = lane >> 3, j = 16 * p + (lane & 7) * 2;
+  // scalar base + 32-bit lane offset (the tile spans < 4 GB): no 64-bit address arithmetic per store
+  auto uniform = [](const gbl_f64* q) {  // (wave-uniform by construction; the compiler cannot see it)
+    const unsigned long long a = (unsigned long long)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (const gbl_f64*)(((unsigned long long)hi << 32) | lo);
+  };
+  const gbl_f64* sbase = uniform(S + (size_t)r0 * ld + c0);
+  const gbl_f64* sslot = uniform(slot);
+  unsigned off_slot = (unsigned)((i0 * NB + j) * 8), off_mat = (unsigned)((i0 * ld + j) * 8);
+  const unsigned step_mat = (unsigned)(8 * ld * 8);
+  const lds_f64* src = &BT[i0 * LDP + j];
+  if (wk == NB) {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {  // first the hand-over slot the panel chain polls ...
+      const int i = i0 + 8 * it;
+      if (i >= rb && i < re) {
+        const f64x2 v = *(const lds_f64x2*)&src[8 * it * LDP];
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(off_slot + 8u * it * NB * 8u), "v"(v), "s"(sslot) : "memory");
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 8; it++) {  // ... then the matrix itself (trailing tiles and the back-substitution read it)
+    const int i = i0 + 8 * it;
+    if (i >= rb && i < re && j < wk) {
+      const f64x2 v = *(const lds_f64x2*)&src[8 * it * LDP];
+      if (j + 1 < wk) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(off_mat), "v"(v), "s"(sbase) : "memory");
+      else asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(off_mat), "v"(v[0]), "s"(sbase) : "memory");
+    }
+    off_mat += step_mat;
+  }
+  // trailing tiles and the back-substitution read the matrix copy only when the whole tile is out: one
+  // acknowledgement wait and one flag, after the last strip (the panel chain polls the hand-over slot instead)
+  if (done_flag != nullptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) cfp_store(done_flag, done_value);
+  }
+}
+
 template <bool PERSIST>
 __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld, int k, int bi, int bj,
                                           int* __restrict__ fail, double lm, double ep,
@@ -607,6 +680,12 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
       __syncthreads();
       if (sp == 3) STAMP(1);
       if (sp == 3 && wave == 0) __builtin_amdgcn_s_setprio(3);
+#ifdef CHOL_WARM
+      if (sp == 1 && wave == 7) {  // experiment: fetch the GEMM helpers' code long before the chain calls them (B2 is not in use yet)
+        wave_gemm_nt16<true>(&B2[48 * LDP + 48], &B2[48 * LDP + 32], &B2[32 * LDP + 48], LDP);
+        wave_gemm_nt16<false>(&B2[48 * LDP + 48], &B2[48 * LDP + 32], &B2[32 * LDP + 48], LDP);
+      }
+#endif
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         if (i < ntile) {
@@ -678,7 +757,11 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
       const int nd = 3 - p;  // diagonal-tile blocks below the pivot block
       if (wave < nd) {
         const int q = p + 1 + wave;
+#ifdef CHOL_INL_EXP
+        wave_gemm_nt16_inl<true>(&B2[(16 * q) * LDP + 16 * p], &B2[(16 * q) * LDP + 16 * p], &Wl[WLB * p], WLP);
+#else
         wave_gemm_nt16<true>(&B2[(16 * q) * LDP + 16 * p], &B2[(16 * q) * LDP + 16 * p], &Wl[WLB * p], WLP);
+#endif
       } else if (solve_rows && wave < nd + 4) {
         const int g = wave - nd;
         wave_gemm_nt16<true>(&BT[(16 * g) * LDP + 16 * p], &BT[(16 * g) * LDP + 16 * p], &Wl[WLB * p], WLP);
@@ -687,38 +770,9 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
     if (p == 0) STAMP(10);
     __syncthreads();
     if (p == 0) STAMP(5);
-    if (PERSIST && solve_rows && wave == 4) {
-      // columns 16p..16p+15 of the solved tile are final: wave 4 (little else to do) writes them through and
-      // publishes the strip; the next block column's workgroups start their rank-16 updates on it right away
-      const int rb = max(r0, c0 + wk), re = min(r0 + NB, nrows);
-      gbl_f64* slot = Ldiag + chol_lfin_offset(n) + (size_t)chol_tile_index((nrows + NB - 1) / NB, bi, kp) * NB * NB;
-#pragma unroll
-      for (int it = 0; it < 8; it++) {  // first the hand-over slot the panel chain polls ...
-        const int u = it * 64 + lane;
-        const int i = u >> 3, j = 16 * p + (u & 7) * 2;
-        if (r0 + i >= rb && r0 + i < re && wk == NB) {
-          const f64x2 v = *(const lds_f64x2*)&BT[i * LDP + j];
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&slot[i * NB + j]), "v"(v) : "memory");
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < 8; it++) {  // ... then the matrix itself (trailing tiles and the back-substitution read it)
-        const int u = it * 64 + lane;
-        const int i = u >> 3, j = 16 * p + (u & 7) * 2;
-        if (r0 + i >= rb && r0 + i < re && j < wk) {
-          gbl_f64* gp = &S[(size_t)(r0 + i) * ld + c0 + j];
-          const f64x2 v = *(const lds_f64x2*)&BT[i * LDP + j];
-          if (j + 1 < wk) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(gp), "v"(v) : "memory");
-          else gstore<true>(gp, v[0]);
-        }
-      }
-      // trailing tiles and the back-substitution read the matrix copy only when the whole tile is out: one
-      // acknowledgement wait and one flag, after the last strip (the panel chain polls the hand-over slot instead)
-      if (p == 3) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) cfp_store(&done[bi], 4 * kp + 3);
-      }
-    }
+    if (PERSIST && solve_rows && wave == 4)
+      chol_strip_out(S, ld, Ldiag + chol_lfin_offset(n) + (size_t)chol_tile_index((nrows + NB - 1) / NB, bi, kp) * NB * NB, BT,
+                     r0, c0, wk, nrows, p, (p == 3) ? &done[bi] : nullptr, 4 * kp + 3);
     if (p == 3) break;
     const int q = p + 1;
     if (wave == 0) {  // the pivot chain: next diagonal block, then its factorisation

@@ -42,8 +42,8 @@ for kp in (8, 12, 16):
     for wg in (0, 1):
         r = st[kp, wg].astype(float) / 100
         print(f"col {kp:2d} wg {wg}: {r[1]-r[0]:6.2f} {r[2]-r[1]:6.2f} {r[3]-r[2]:6.2f} {r[4]-r[3]:6.2f} {r[10]-r[4]:6.2f} {r[5]-r[10]:6.2f} {r[6]-r[5]:6.2f} {r[7]-r[6]:6.2f} {r[8]-r[7]:6.2f} {r[13]-r[8]:6.2f}")
-print("inside wave 0's first solve GEMM (diagnostic build only): barrier -> operands loaded | 4 MFMAs | stores + return")
+print("inside wave 0's first solve GEMM (diagnostic build only): barrier -> function entered | operands loaded | 4 MFMAs | stores + return")
 for kp in (8, 12, 16):
     for wg in (0, 1):
         r = st[kp, wg].astype(float) / 100
-        print(f"col {kp:2d} wg {wg}: {r[14]-r[4]:6.2f} {r[15]-r[14]:6.2f} {r[10]-r[15]:6.2f}")
+        print(f"col {kp:2d} wg {wg}: {r[9]-r[4]:6.2f} {r[14]-r[9]:6.2f} {r[15]-r[14]:6.2f} {r[10]-r[15]:6.2f}")
