@@ -93,6 +93,25 @@ def test_solver_launch_modes_agree(env):
     assert worst < 1e-10, (env, worst)
 
 
+@pytest.mark.parametrize("n", [6, 42, 63, 64, 65, 127, 129, 378, 641, 1025, 1530, 1536, 2046])
+def test_solver_size_sweep(backends, n):
+    """Sizes around the 64-column tile and 16-column strip boundaries (partial last block column, single tile, one
+    column past a tile), through the single-launch factorisation and back-substitution: numpy to 1e-10."""
+    torch = _torch()
+    lib = backends._lib.load()
+    A, b = _spd(n, 100 + n)
+    dA, dbv = torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()
+    x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(lib.droid_chol_scratch_doubles(n), dtype=torch.float64, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert lib.droid_chol_solve(dA.data_ptr(), dbv.data_ptr(), x.data_ptr(), n, scratch.data_ptr(), flag.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    ref = np.linalg.solve(A, b)
+    assert np.abs(x.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-10
+
+
 def test_violation_is_raised_by_the_next_call_without_sync(backends):
     """eta with one row too few: the device flags it (status bit 1 << 1); nothing raises in the offending call
     (no synchronisation on the hot path), the next `ba` on the same stream raises, and the one after is clean."""
