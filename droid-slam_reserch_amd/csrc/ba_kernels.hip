@@ -1223,9 +1223,34 @@ __global__ __launch_bounds__(256, 3) void ba_schur2_kernel(BaView v, const float
     __syncthreads();
     prefetch(tile + 1);
     // ---- SYRK of the tile: wave w owns Gram tiles w, w+4, ...; one fp32 chain per 64-pixel tile, fp64 totals
+    // Two Gram tiles of a wave at a time: each keeps its ONE fp32 chain (same sums as before, bit for bit), but the two chains
+    // alternate on the matrix pipe and share the wait for their operand reads -- one tile after the other left the pipe
+    // idle for the LDS latency twice per tile and for the latency of every dependent MFMA.
 #pragma unroll
-    for (int t = 0; t < S2_MAXT; t++) {
-      if (wave + 4 * t < ntiles) {
+    for (int t = 0; t < S2_MAXT; t += 2) {
+      const bool two = (t + 1 < S2_MAXT) && (wave + 4 * (t + 1) < ntiles);  // wave-uniform
+      if (two) {
+        const float* pa0 = &EB[toff_a[t]];
+        const float* pb0 = &EB[toff_b[t]];
+        const float* pa1 = &EB[toff_a[t + 1 < S2_MAXT ? t + 1 : t]];
+        const float* pb1 = &EB[toff_b[t + 1 < S2_MAXT ? t + 1 : t]];
+        f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < SF_TP; s4 += 16) {
+          const f32x4 av0 = *reinterpret_cast<const f32x4*>(pa0 + s4), bv0 = *reinterpret_cast<const f32x4*>(pb0 + s4);
+          const f32x4 av1 = *reinterpret_cast<const f32x4*>(pa1 + s4), bv1 = *reinterpret_cast<const f32x4*>(pb1 + s4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[e], bv0[e], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], bv1[e], c1, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+          tot[t][x] += (double)c0[x];
+          tot[t + 1 < S2_MAXT ? t + 1 : t][x] += (double)c1[x];
+        }
+      } else if (wave + 4 * t < ntiles) {
         // 16-byte operand reads; K runs in a permuted order (k-step (s,e) of lane group g = pixel 16s+4g+e),
         // identical for both operands
         const float* pa = &EB[toff_a[t]];
