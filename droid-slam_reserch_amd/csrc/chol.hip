@@ -406,9 +406,11 @@ __device__ __forceinline__ void frag_load_tile(f64x4& acc, const gbl_f64* __rest
 // acc (16x16 fragment) -= A(16x16 LDS block) * B(16x16 LDS block)^T, both with row pitch LDP
 __device__ __forceinline__ void block_update16(f64x4& acc, const lds_f64* A, const lds_f64* B) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  double av[4], bv[4];  // all eight operands in flight before the first product (the volatile reads otherwise wait pair by pair)
 #pragma unroll
-  for (int kk = 0; kk < 16; kk += 4)
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lds_operand(&A[r * LDP + kk + g]), lds_operand(&B[r * LDP + kk + g]), acc, 0, 0, 0);
+  for (int k = 0; k < 4; k++) { av[k] = lds_operand(&A[r * LDP + 4 * k + g]); bv[k] = lds_operand(&B[r * LDP + 4 * k + g]); }
+#pragma unroll
+  for (int k = 0; k < 4; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[k], bv[k], acc, 0, 0, 0);
 }
 
 // One step of the blocked right-looking factorisation in ONE launch of 512-thread workgroups:
