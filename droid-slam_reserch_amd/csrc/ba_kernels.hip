@@ -674,11 +674,15 @@ __global__ __launch_bounds__(256) void ba_lin_finish_kernel(BaView v, const floa
 // Restates Hs/vs layout :400-423 and SparseBlock::update_lhs/update_rhs :1131-1173 (blocks of
 // frames before t0 are dropped; indices >= P, undefined in the reference, are dropped too).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ba_assemble_kernel(BaView v, const float* __restrict__ poses,
-                                                          const int64_t* __restrict__ ii,
-                                                          const int64_t* __restrict__ jj) {
-  __shared__ double hj[6][6], vj[6], A[6][6], hij[6][6];
-  const int e = blockIdx.x, t = threadIdx.x;
+struct AssembleScratch {  // per WAVE
+  double hj[6][6], vj[6], A[6][6], hij[6][6];
+};
+// One virtual workgroup (= one wave) of the assemble step: edge e (or a solver-preset unit for e >= v.E), lane t.
+// Wave-level only (no workgroup barrier), so that it can run as a stand-alone 64-thread kernel (motion-only BA) or in
+// spare workgroups of ba_schur2_kernel, four virtual workgroups per 256-thread workgroup.
+__device__ __forceinline__ void assemble_unit(const BaView& v, const float* __restrict__ poses, const int64_t* __restrict__ ii,
+                                              const int64_t* __restrict__ jj, int e, int t, AssembleScratch& sh) {
+  auto& hj = sh.hj; auto& vj = sh.vj; auto& A = sh.A; auto& hij = sh.hij;
   if (e >= v.E) {
     // spare workgroups preset the solver's scratch for this iteration (saves two fill launches in front of the
     // factorisation): solution vector and hand-off flags to 0xFF bytes, the failure flag to 0
@@ -724,7 +728,8 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaView v, const float* 
     adjT_mat(T.R, T.t, X, Y);
     for (int r = 0; r < 6; r++) A[r][k] = Y[r];
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations are ordered
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int n = v.n;
   if (t < 36) {
     const int r = t / 6, c = t % 6;
@@ -732,7 +737,8 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaView v, const float* 
     for (int k = 0; k < 6; k++) s -= A[r][k] * hj[k][c];  // Hij = -A Hjj
     hij[r][c] = s;
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations are ordered
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (t < 36) {
     const int r = t / 6, c = t % 6;
     if (vj_ok && r >= c) atomicAdd(sys_at(v, 6 * pj + r, 6 * pj + c), hj[r][c]);
@@ -756,6 +762,12 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaView v, const float* 
       atomicAdd(sys_at(v, n, 6 * pi + r), s);
     }
   }
+}
+__global__ __launch_bounds__(64) void ba_assemble_kernel(BaView v, const float* __restrict__ poses,
+                                                          const int64_t* __restrict__ ii,
+                                                          const int64_t* __restrict__ jj) {
+  __shared__ AssembleScratch sh;
+  assemble_unit(v, poses, ii, jj, (int)blockIdx.x, (int)threadIdx.x, sh);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1109,9 +1121,19 @@ __global__ __launch_bounds__(256, 3) void ba_schur2_kernel(BaView v, const float
                                                            const float* __restrict__ disps,
                                                            const float* __restrict__ intrinsics,
                                                            const float* __restrict__ weights,
-                                                           const int64_t* __restrict__ jj, int wide) {
+                                                           const int64_t* __restrict__ ii,
+                                                           const int64_t* __restrict__ jj, int wide, int asm_units) {
   __shared__ __attribute__((aligned(16))) float EB[6 * S2_MAXE * SF_PITCH];
   __shared__ Schur2Meta sm;
+  if ((int)blockIdx.x >= v.M) {
+    // spare workgroups (x >= M): the assemble step of this iteration (per-edge pose blocks -> reduced system, solver scratch
+    // presets), four wave-sized units per workgroup.  Independent of the Schur products (both only add into the system), so it
+    // hides inside this launch instead of holding a 9 us launch of its own in front of it.
+    AssembleScratch* sh = reinterpret_cast<AssembleScratch*>(EB);
+    const int unit = (((int)blockIdx.x - v.M) * (int)gridDim.y + (int)blockIdx.y) * 4 + (int)(threadIdx.x >> 6);
+    if (unit < asm_units) assemble_unit(v, poses, ii, jj, unit, (int)(threadIdx.x & 63), sh[threadIdx.x >> 6]);
+    return;
+  }
   if ((int)blockIdx.x >= min(v.hdr[HDR_M], v.M)) return;
   const int m = v.order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1877,8 +1899,8 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
       }
       break;
     }
-    case 1:
-      if (v.E > 0)
+    case 1:  // (with depth slots the assemble step rides in spare workgroups of the Schur launch, stage 2)
+      if (v.E > 0 && !depth)
         hipLaunchKernelGGL(ba_assemble_kernel, dim3(v.E + (solver_preset_words(v) + 1023) / 1024 + solver_preset_tiles(v)), dim3(64), 0, s, v, poses, ii, jj);
       break;
     case 2:
@@ -1891,7 +1913,10 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
         // ranks) send their slots of 17..85 entries to the wide kernels
         const int wide = v.wide;
         // sparse slots (<= S2_MAXE edges): Gram tiles per pixel range, then the per-slot fold
-        hipLaunchKernelGGL(ba_schur2_kernel, dim3(v.M, v.s2_split), dim3(256), 0, s, v, poses, disps, intr, weights, jj, wide);
+        const int asm_units = v.E > 0 ? v.E + (solver_preset_words(v) + 1023) / 1024 + solver_preset_tiles(v) : 0;
+        const int asm_x = (asm_units + 4 * v.s2_split - 1) / (4 * v.s2_split);  // spare columns of the grid
+        hipLaunchKernelGGL(ba_schur2_kernel, dim3(v.M + asm_x, v.s2_split), dim3(256), 0, s, v, poses, disps, intr, weights, ii, jj,
+                           wide, asm_units);
         hipLaunchKernelGGL(ba_schur_fold_kernel, dim3(v.M), dim3(1024), 0, s, v, poses, jj, v.s2_split);
         hipLaunchKernelGGL(ba_schur_fused_kernel<true>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
                            intr, weights, ii, jj, wide);
