@@ -107,7 +107,7 @@ def bench_ba(args, rank, world, dev, N, E, H=48, W=64, stereo=False, lm=1e-5, ep
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     st, m = solver.backend.status()
-    if st & 3:
+    if st & 11:
         raise RuntimeError(f"BA reported contract violation status={st}")
 
     info = dict(N=N, E=E, E_local=int(p.ii.shape[0]), M_local=int(p.eta.shape[0]), HW=H * W, P=prob.t1 - prob.t0,

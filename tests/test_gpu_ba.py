@@ -28,7 +28,7 @@ def _check(backends, oracle, p, iterations, motion_only=False, tol=TOL, tag=""):
     torch = _torch()
     hip = run_hip_ba(backends, p, torch, iterations, motion_only)
     ref = oracle.ba(*ba_args(p), iterations, p.lm, p.ep, motion_only, storage_f32=True)
-    assert hip["status"] & 3 == 0, f"device status {hip['status']}"
+    assert hip["status"] & 11 == 0, f"device status {hip['status']}"
     if not motion_only:
         assert hip["M"] == ref["M"]
     et, er, ed = compare_state(hip, ref, tag)

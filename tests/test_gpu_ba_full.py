@@ -5,7 +5,8 @@ Everything goes through droid_backends.ba -> C ABI.  Tolerance 1e-4 (north star)
 import numpy as np
 import pytest
 
-from util import assert_composite_parity, ba_args, compare_state, run_hip_ba, stepwise_parity, to_dev
+from util import (assert_composite_parity, ba_args, compare_state, run_hip_ba, sensitive_disparities,
+                  stepwise_parity, to_dev)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -35,13 +36,13 @@ def _copy(p):
 
 def _parity(backends, oracle, p, iterations, tag):
     """(1) every iteration strictly within TOL of the oracle from identical inputs; (2) the composite call:
-    poses strictly, disparities with the measured allowance for ill-conditioned depths (tests/util.py);
-    (3) the composite call equals the chained single-iteration calls bit for bit."""
+    every pose and EVERY pixel strictly within TOL of `oracle.ba(storage_f32=True)` (SURVEY 8d's metric, no
+    allowance); (3) the composite call equals the chained single-iteration calls."""
     torch = _torch()
     chained, _ = stepwise_parity(backends, oracle, p, torch, iterations, TOL, tag)
     hip = run_hip_ba(backends, p, torch, iterations)
     ref = oracle.ba(*ba_args(p), iterations, p.lm, p.ep, False, storage_f32=True)
-    assert hip["status"] & 3 == 0
+    assert hip["status"] & 11 == 0
     assert hip["M"] == ref["M"]
     if iterations == 1:
         et, er, ed = compare_state(hip, ref, tag)
@@ -66,12 +67,13 @@ def test_cfg3_seed_sweep_margin(backends, oracle, synth, seed):
 
 
 def test_cfg4_256kf_8000e_matches_oracle(backends, oracle, synth):
-    """Dense graph: 31 edges per source frame on average exercises the multi-block Schur path."""
-    _parity(backends, oracle, synth.make_config("cfg4"), 1, "cfg4")
+    """Dense graph: 31 edges per source frame on average exercises the multi-block Schur path.  Two iterations:
+    SURVEY 8d's parity metric is "after ba(iterations=2)"."""
+    _parity(backends, oracle, synth.make_config("cfg4"), 2, "cfg4")
 
 
 def test_cfg5_stereo_96x128_matches_oracle(backends, oracle, synth):
-    _parity(backends, oracle, synth.make_config("cfg5"), 1, "cfg5")
+    _parity(backends, oracle, synth.make_config("cfg5"), 2, "cfg5")
 
 
 def test_dense_graph_syrk_kernels_match_oracle(backends, oracle, synth):
@@ -92,7 +94,16 @@ def test_dense_graph_block_pair_kernel_matches_oracle(backends, oracle, synth):
     _parity(backends, oracle, p, 2, "dense 30kf/720e 15x20")
 
 
-def test_cfg3_edge_permutation_invariance(backends, cfg3):
+@pytest.fixture(scope="module")
+def cfg3_sensitive(oracle, cfg3):
+    """Ill-conditioned disparities of the headline graph over two iterations, measured with the oracle alone."""
+    m = sensitive_disparities(oracle, cfg3, 2, TOL)
+    print(f"cfg3: {int(m.sum())} of {m.size} disparities are sensitive to the float32 rounding of the state")
+    assert m.sum() <= 2e-4 * m.size      # the set is tiny: an allowance inside it cannot hide a regression
+    return m
+
+
+def test_cfg3_edge_permutation_invariance(backends, cfg3, cfg3_sensitive):
     """The solution does not depend on the order of the edge list (only summation order changes)."""
     torch = _torch()
     a = run_hip_ba(backends, _copy(cfg3), torch, 2)
@@ -100,13 +111,13 @@ def test_cfg3_edge_permutation_invariance(backends, cfg3):
     perm = np.random.default_rng(3).permutation(len(q.ii))
     q.ii, q.jj, q.targets, q.weights = q.ii[perm], q.jj[perm], q.targets[perm], q.weights[perm]
     b = run_hip_ba(backends, q, torch, 2)
-    assert_composite_parity(a, b, TOL, "perm x2")
+    assert_composite_parity(a, b, TOL, "perm x2", sensitive=cfg3_sensitive)
     a1, b1 = run_hip_ba(backends, _copy(cfg3), torch, 1), run_hip_ba(backends, q, torch, 1)
     et, er, ed = compare_state(a1, b1, "perm x1")
     assert et < 1e-5 and er < 1e-5 and ed < 2e-5   # one iteration: only summation order differs
 
 
-def test_cfg3_duplicated_edges_equal_doubled_weights(backends, cfg3):
+def test_cfg3_duplicated_edges_equal_doubled_weights(backends, oracle, cfg3):
     """Linearity of the normal equations in the weights: listing an edge twice == doubling its weight."""
     torch = _torch()
     k = 300
@@ -119,7 +130,7 @@ def test_cfg3_duplicated_edges_equal_doubled_weights(backends, cfg3):
     b.targets = np.concatenate([b.targets, b.targets[:k]])
     b.weights = np.concatenate([b.weights, b.weights[:k]])
     rb = run_hip_ba(backends, b, torch, 2)
-    assert_composite_parity(ra, rb, TOL, "dup x2")
+    assert_composite_parity(ra, rb, TOL, "dup x2", sensitive=sensitive_disparities(oracle, a, 2, TOL))
     ra1, rb1 = run_hip_ba(backends, a, torch, 1), run_hip_ba(backends, b, torch, 1)
     et, er, ed = compare_state(ra1, rb1, "dup x1")
     assert et < 1e-5 and er < 1e-5 and ed < 2e-5
@@ -172,7 +183,7 @@ def test_empty_graph_is_a_noop(backends, synth):
         np.full((p.t1 - p.t0,) + p.disps.shape[1:], 1e-3, np.float32)
     poses0, disps0 = p.poses.copy(), p.disps.copy()
     hip = run_hip_ba(backends, p, torch, 2)
-    assert hip["status"] & 3 == 0
+    assert hip["status"] & 11 == 0
     assert np.abs(hip["poses"] - poses0).max() == 0
     assert np.abs(hip["disps"] - disps0).max() == 0
     assert np.abs(hip["dx"]).max() == 0

@@ -132,7 +132,7 @@ def test_violation_is_raised_by_the_next_call_without_sync(backends):
         backends.ba(*args(d["eta"]))
     backends.ba(*args(d["eta"]))               # reported once; this call runs
     torch.cuda.synchronize()
-    assert backends.ba_status()[0] & 3 == 0
+    assert backends.ba_status()[0] & 11 == 0
 
 
 def test_workspaces_are_per_stream(backends):

@@ -76,7 +76,7 @@ def test_two_rank_hip_ba_matches_single_and_oracle(tmp_path, backends, oracle, k
     ref = oracle.ba(*ba_args(prob), 2, prob.lm, prob.ep, False, storage_f32=True)
     outs = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(2)]
     for o in outs:
-        assert int(o["status"]) & 3 == 0 and int(o["M"]) == int(o["M_expected"])
+        assert int(o["status"]) & 11 == 0 and int(o["M"]) == int(o["M_expected"])
         assert np.abs(o["poses"] - outs[0]["poses"]).max() == 0.0  # replicated solve is bit-identical
         # sharded vs single GPU: the partial systems are summed in a different order (float32 linearisation
         # partials are identical, the fp64 reduction is not): float32 resolution of the state times the graph's
@@ -85,3 +85,74 @@ def test_two_rank_hip_ba_matches_single_and_oracle(tmp_path, backends, oracle, k
         assert np.abs(o["disps"] - single["disps"]).max() < 1e-4
         assert np.abs(o["poses"] - ref["poses"]).max() < 1e-4
         assert np.abs(o["disps"] - ref["disps"]).max() < 1e-4
+
+
+def test_cfg4_eight_shards_in_one_process(backends, oracle):
+    """BASELINE configs[3] -- 256 keyframes / 8000 edges -- through the SHARDED code path, all eight shards of
+    the partition `bench.py --gpus 8` builds, in one process on one GPU (droid_kernels.cu:1357-1431 is
+    the loop each rank runs): rank r = 0..7 gets its own workspace, poses / disps replicas and `own` range; per
+    iteration every shard runs `build_packed`, the eight packed systems are summed on the device (what the RCCL
+    all-reduce does), every shard unpacks the sum and runs `solve_update`.  Checks: (1) the summed system equals
+    the unsharded build of the same graph -- the only differences are float32 summation orders of `C`/`w` inside a
+    slot (the sharded linearisation splits a slot's edges over workgroups, `zsplit`) and the fp64 order of the
+    reduction; (2) all shards hold bit-identical poses; (3) the final state matches the fp64 oracle < 1e-4 and
+    the unsharded device run."""
+    import torch
+    from droid_backends import ba_driver, synth
+    from util import ba_args, run_hip_ba
+    assert torch.cuda.is_available()
+    world, iters = 8, 2
+    prob = synth.make_config("cfg4")
+    ranges = ba_driver.partition_frames(prob.ii, prob.t1, world)
+    assert ranges[0][0] == 0 and ranges[-1][1] == prob.t1 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    shards, probs, bes = [], [], []
+    for r in range(world):
+        sh = ba_driver.shard_problem(prob, ranges, r)
+        shards.append(sh)
+        probs.append(ba_driver.BAProblemDev(poses=t(prob.poses), disps=t(prob.disps), intrinsics=t(prob.intrinsics),
+                                            disps_sens=t(prob.disps_sens), targets=t(sh["targets"]),
+                                            weights=t(sh["weights"]), eta=t(sh["eta"]), ii=t(sh["ii"]), jj=t(sh["jj"])))
+        bes.append(ba_driver.HipBackend())
+    assert sum(len(sh["ii"]) for sh in shards) == len(prob.ii) == 8000
+    assert sum(sh["eta"].shape[0] for sh in shards) == prob.eta.shape[0]
+    full = ba_driver.BAProblemDev(poses=t(prob.poses), disps=t(prob.disps), intrinsics=t(prob.intrinsics),
+                                  disps_sens=t(prob.disps_sens), targets=t(prob.targets), weights=t(prob.weights),
+                                  eta=t(prob.eta), ii=t(prob.ii), jj=t(prob.jj))
+    whole = ba_driver.HipBackend()
+    whole.prepare(full, prob.t0, prob.t1, (0, prob.t1), False)
+    for r in range(world):
+        bes[r].prepare(probs[r], prob.t0, prob.t1, shards[r]["own"], False)
+    for it in range(iters):
+        total = None
+        for r in range(world):
+            packed = bes[r].build_packed(probs[r], False)
+            total = packed.clone() if total is None else total + packed
+        if it == 0:   # same state on both sides: compare the reduced camera systems entry-wise
+            ref_sys = whole.build_packed(full, False).clone()
+            torch.cuda.synchronize()
+            scale = float(ref_sys.abs().max())
+            err = float((total - ref_sys).abs().max()) / scale
+            print(f"8-shard sum vs unsharded system: max |diff| / max |entry| = {err:.3e} (max entry {scale:.3e})")
+            assert err < 2e-7, err
+        for r in range(world):
+            bes[r].packed.copy_(total)
+            bes[r].unpack(False)
+            bes[r].solve_update(probs[r], prob.lm, prob.ep, False)
+    torch.cuda.synchronize()
+    disps = np.array(prob.disps, copy=True)
+    for r in range(world):
+        st, m = bes[r].status()
+        assert st & 11 == 0 and m == shards[r]["eta"].shape[0], (r, st, m)
+        assert torch.equal(probs[r].poses, probs[0].poses)       # replicated solve: bit-identical
+        f0, f1 = ranges[r]
+        disps[f0:f1] = probs[r].disps[f0:f1].cpu().numpy()
+    poses = probs[0].poses.cpu().numpy()
+    ref = oracle.ba(*ba_args(prob), iters, prob.lm, prob.ep, False, storage_f32=True)
+    single = run_hip_ba(backends, prob, torch, iters)
+    ep, ed = np.abs(poses - ref["poses"]).max(), np.abs(disps - ref["disps"]).max()
+    sp, sd = np.abs(poses - single["poses"]).max(), np.abs(disps - single["disps"]).max()
+    print(f"8 shards vs oracle: poses {ep:.3e} disps {ed:.3e}; vs unsharded device run: poses {sp:.3e} disps {sd:.3e}")
+    assert ep < 1e-4 and ed < 1e-4
+    assert sp < 5e-5 and sd < 1e-4

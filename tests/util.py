@@ -52,7 +52,7 @@ def stepwise_parity(backends, oracle, p, torch, iterations, tol, tag=""):
     for k in range(iterations):
         hip = run_hip_ba(backends, q, torch, 1)
         ref = oracle.ba(*ba_args(q), 1, q.lm, q.ep, False, storage_f32=True)
-        assert hip["status"] & 3 == 0 and hip["M"] == ref["M"]
+        assert hip["status"] & 11 == 0 and hip["M"] == ref["M"]
         et, er, ed = compare_state(hip, ref, f"{tag} iteration {k + 1} from the device state")
         assert et < tol and er < tol and ed < tol, (tag, k, et, er, ed)
         worst = [max(a, b) for a, b in zip(worst, (et, er, ed))]
@@ -60,19 +60,53 @@ def stepwise_parity(backends, oracle, p, torch, iterations, tol, tag=""):
     return q, worst
 
 
-def assert_composite_parity(hip, ref, tol, tag="", per_million=8, hard=2e-3):
-    """Composite (multi-iteration) parity: poses strictly within tol; disparities within tol except for at most
-    `per_million` pixels per million, none beyond `hard`.  Why an allowance: a weakly observed depth (C ~ eta,
-    update of 100 % of its value) amplifies a 1-ulp float32 change of the state after iteration 1 by up to ~1e3 in
-    iteration 2 -- measured with the oracle ALONE: rounding its intermediate state to float32, which the
-    reference's float tensors do, moves such a pixel by 5.4e-5 (cfg3 seed 12, pixel (238,1,27)).  Any two float32
-    evaluations (device vs oracle, two edge orders, the reference itself) differ there by ~1e-4; every other pixel
-    and every pose is held to tol."""
+def sensitive_disparities(oracle, p, iterations, tol, probes=2, seed=0):
+    """The ill-conditioned set of a multi-iteration call, measured with the ORACLE ALONE: pixels whose result
+    after `iterations` iterations moves by more than tol/4 when nothing but the float32 rounding of the state
+    between iterations changes -- (a) fp64 state vs float32 state (`storage_f32`), (b) the float32 state after
+    the first iteration nudged by one float32 ulp in a random direction (`probes` draws).  A weakly observed
+    depth (C ~ eta, update of 100 % of its value) amplifies a 1-ulp change of the state after iteration 1 by up
+    to ~1e3 in iteration 2 (cfg3 seed 12, pixel (238,1,27): 5.4e-5).  Any two float32-state evaluations (two edge
+    orders on the device, the reference itself) may differ there by ~1e-4; nowhere else.  Returns a bool mask
+    shaped like disps."""
+    import copy
+    base = oracle.ba(*ba_args(p), iterations, p.lm, p.ep, False, storage_f32=True)
+    f64s = oracle.ba(*ba_args(p), iterations, p.lm, p.ep, False, storage_f32=False)
+    mask = np.abs(base["disps"] - f64s["disps"]) > tol / 4
+    if iterations >= 2:
+        first = oracle.ba(*ba_args(p), 1, p.lm, p.ep, False, storage_f32=True)
+        rng = np.random.default_rng(seed)
+        for _ in range(probes):
+            q = copy.deepcopy(p)
+            d32 = first["disps"].astype(np.float32)
+            p32 = first["poses"].astype(np.float32)
+            q.disps = np.where(rng.random(d32.shape) < 0.5, np.nextafter(d32, np.float32(np.inf)),
+                               np.nextafter(d32, np.float32(-np.inf))).astype(np.float32)
+            q.poses = np.where(rng.random(p32.shape) < 0.5, np.nextafter(p32, np.float32(np.inf)),
+                               np.nextafter(p32, np.float32(-np.inf))).astype(np.float32)
+            q.poses[:p.t0] = p32[:p.t0]
+            r = oracle.ba(*ba_args(q), iterations - 1, p.lm, p.ep, False, storage_f32=True)
+            mask |= np.abs(r["disps"] - base["disps"]) > tol / 4
+    return mask
+
+
+def assert_composite_parity(hip, ref, tol, tag="", sensitive=None, hard=2e-3):
+    """Composite (multi-iteration) parity.  Device vs ORACLE (`sensitive` None): every pose and EVERY pixel
+    strictly within tol -- the north star's bar, no allowance.  Device vs DEVICE (two float32 evaluations of one
+    problem: edge permutation, duplicated edges): pixels of the oracle-measured ill-conditioned set
+    (`sensitive_disparities`) may differ by up to `hard`; every pixel outside it and every pose is held to tol.
+    The outlier count is printed so that drift is visible."""
     et, er, ed = compare_state(hip, ref, tag)
     d = np.abs(hip["disps"] - ref["disps"])
-    n_out = int((d > tol).sum())
-    allow = max(2, int(per_million * 1e-6 * d.size))
-    print(f"[{tag}] disparities beyond {tol:g}: {n_out} of {d.size} (allowed {allow}), max {d.max():.3e}")
+    over = d > tol
+    n_out = int(over.sum())
     assert et < tol and er < tol, (tag, et, er)
-    assert n_out <= allow and d.max() < hard, (tag, n_out, allow, float(d.max()))
+    if sensitive is None:
+        print(f"[{tag}] disparities beyond {tol:g}: {n_out} of {d.size} (strict), max {d.max():.3e}")
+        assert n_out == 0, (tag, n_out, float(d.max()))
+    else:
+        stray = int((over & ~sensitive).sum())
+        print(f"[{tag}] disparities beyond {tol:g}: {n_out} of {d.size}, {stray} outside the ill-conditioned set "
+              f"({int(sensitive.sum())} pixels), max {d.max():.3e}")
+        assert stray == 0 and d.max() < hard, (tag, n_out, stray, float(d.max()))
     return et, er, ed, n_out
