@@ -19,9 +19,9 @@ int launch_corr_pyramid_forward(const void* const* volumes, const float* coords,
                                 int r, int levels, int dtype, hipStream_t s);
 int launch_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad, int B,
                                int H1, int W1, int H2, int W2, int r, int dtype, hipStream_t s);
-int launch_altcorr_pyramid_forward(const float* const* levels_dev, const int64_t* ii, const int64_t* jj,
+int launch_altcorr_pyramid_forward(const void* const* levels_dev, const int64_t* ii, const int64_t* jj,
                                    const float* coords, float* corr, int E, int frames, int H, int W, int C,
-                                   int r, int nlevels, hipStream_t s);
+                                   int r, int nlevels, int dtype, hipStream_t s);
 int launch_altcorr_forward(const void* f1, const void* f2, const float* coords, void* corr, int B,
                            int N, int H1, int W1, int H2, int W2, int C, int r, int dtype,
                            hipStream_t s);
@@ -135,19 +135,32 @@ int droid_altcorr_forward(const void* fmap1, const void* fmap2, const float* coo
   return check_hip("altcorr_forward");
 }
 
-int droid_altcorr_pyramid_forward(const float* const* pyramid, const int64_t* ii, const int64_t* jj,
-                                  const float* coords, float* corr, int E, int frames, int H, int W,
-                                  int C, int radius, int levels, void* stream) {
+static int altcorr_pyramid_any(const void* const* pyramid, const int64_t* ii, const int64_t* jj,
+                               const float* coords, float* corr, int E, int frames, int H, int W,
+                               int C, int radius, int levels, int dtype, void* stream) {
   if (E < 0 || frames <= 0 || H <= 0 || W <= 0 || C <= 0 || levels < 1 || levels > 4)
     return fail(DROID_E_ARG, "altcorr_pyramid_forward: bad %s", "shape");
   if (E == 0) return DROID_OK;
   if (!pyramid || !ii || !jj || !coords || !corr) return fail(DROID_E_ARG, "altcorr_pyramid_forward: null %s", "pointer");
   for (int l = 0; l < levels; l++)
     if (!pyramid[l]) return fail(DROID_E_ARG, "altcorr_pyramid_forward: null %s", "pyramid level");
-  int rc = launch_altcorr_pyramid_forward(pyramid, ii, jj, coords, corr, E, frames, H, W, C, radius, levels,
+  int rc = launch_altcorr_pyramid_forward(pyramid, ii, jj, coords, corr, E, frames, H, W, C, radius, levels, dtype,
                                           (hipStream_t)stream);
-  if (rc) return fail(rc, "altcorr_pyramid_forward: %s", "unsupported configuration (fp32, C % 16 == 0, C <= 128, r in {3,4})");
+  if (rc) return fail(rc, "altcorr_pyramid_forward: %s", "unsupported configuration (C % 16 (fp32) / 32 (fp16) == 0, C <= 128, r in {3,4})");
   return check_hip("altcorr_pyramid_forward");
+}
+
+int droid_altcorr_pyramid_forward(const float* const* pyramid, const int64_t* ii, const int64_t* jj,
+                                  const float* coords, float* corr, int E, int frames, int H, int W,
+                                  int C, int radius, int levels, void* stream) {
+  return altcorr_pyramid_any(reinterpret_cast<const void* const*>(pyramid), ii, jj, coords, corr, E, frames, H, W, C,
+                             radius, levels, DROID_F32, stream);
+}
+
+int droid_altcorr_pyramid_forward_f16(const void* const* pyramid, const int64_t* ii, const int64_t* jj,
+                                      const float* coords, float* corr, int E, int frames, int H, int W,
+                                      int C, int radius, int levels, void* stream) {
+  return altcorr_pyramid_any(pyramid, ii, jj, coords, corr, E, frames, H, W, C, radius, levels, DROID_F16, stream);
 }
 
 int droid_altcorr_backward(const float* fmap1, const float* fmap2, const float* coords,

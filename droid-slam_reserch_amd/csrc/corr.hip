@@ -746,8 +746,25 @@ __device__ unsigned long long g_am_stamps[768 * 4 * 32];
 #define AMNOTE(slot, v) do { } while (0)
 #endif
 constexpr int AM_TX = 16, AM_TY = 4;     // query tile of a workgroup
-constexpr int AM_CH = 16;                // channels per stage
-constexpr int AM_MAXSTAGE = 8;           // C <= 128 on this path
+// Input element type of the matrix-core path.  A stage is 64 bytes per position whatever the type, so the LDS
+// image, the swizzle and the DMA plan are shared: fp32 = 16 channels per stage on v_mfma_f32_16x16x4_f32 (4 k-steps
+// per stage), fp16 = 32 channels per stage on ONE v_mfma_f32_16x16x32_f16 (16x the fp32 matrix rate; products of
+// two halves are exact in fp32, accumulation is fp32, so the half path reproduces the reference's
+// `.float()` evaluation of half feature maps -- modules/corr.py:120 -- up to summation order).
+template <typename TI> struct AmIn;
+template <> struct AmIn<float> {
+  static constexpr int EPC = 4;            // elements per 16-byte chunk
+  static constexpr int CH = 16;            // channels per stage
+  static constexpr int MAXSTAGE = 8;       // C <= 128 on this path
+};
+template <> struct AmIn<__half> {
+  static constexpr int EPC = 8;
+  static constexpr int CH = 32;
+  static constexpr int MAXSTAGE = 4;       // C <= 128
+};
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void am_store(float* p, float v) { *p = v; }
+__device__ __forceinline__ void am_store(__half* p, float v) { *p = __float2half_rn(v); }
 constexpr int AM_MAXBLK = 15;            // 16-position blocks per wave (240 positions >= 15x16)
 // D exchange: r=3 keeps 12 blocks per round (50 KB of LDS, 3 workgroups per CU; a second round serves
 // blocks 13..15 of strongly diverging windows); r=4 windows need 13+ blocks even for a smooth flow
@@ -775,14 +792,16 @@ __device__ __forceinline__ int wave_max16(int v) {
 // Body shared by the two entry points below.  f1e / f2b: feature maps of this edge (channels last),
 // cbase: its query coordinates, multiplied by cscale (1, or 2^-level for the pyramid entry point:
 // exact), oute: its (2r+1)^2 output planes, tile: index of the 16x4 query tile.
-template <int R>
-__device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e, const float* __restrict__ f2b,
+template <int R, typename TI, typename TO>
+__device__ __forceinline__ void altcorr_mfma_body(const TI* __restrict__ f1e, const TI* __restrict__ f2b,
                                                   const float* __restrict__ cbase, const float cscale,
-                                                  float* __restrict__ oute, const int tile, const int H1,
+                                                  TO* __restrict__ oute, const int tile, const int H1,
                                                   const int W1, const int H2, const int W2, const int C) {
   constexpr int RD = 2 * R + 1, NT = RD + 1;
+  constexpr int AM_CH = AmIn<TI>::CH, AM_EPC = AmIn<TI>::EPC, AM_MAXSTAGE = AmIn<TI>::MAXSTAGE;
+  constexpr bool HALF_IN = AM_EPC == 8;
   constexpr int AM_XBLK = AmCfg<R>::XBLK, AM_CP = AmCfg<R>::CP, AM_LDS_FLOATS = AmCfg<R>::LDS_FLOATS;
-  static_assert(AM_MAXPOS * AM_CH <= AM_LDS_FLOATS, "one stage of the largest box must fit");
+  static_assert(AM_MAXPOS * 16 <= AM_LDS_FLOATS, "one stage (64 bytes per position) of the largest box must fit");
   __shared__ __attribute__((aligned(16))) float lds[AM_LDS_FLOATS];
   __shared__ int sbox[4][4];  // per wave: x0, y0, width, height of its (clipped) box
   const int tid = threadIdx.x, lane = tid & 63;
@@ -804,7 +823,7 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
   float2 gc = *reinterpret_cast<const float2*>(cbase + 2 * gpix);
   f4 a_all[AM_MAXSTAGE];  // this lane's A fragments of all stages: channels 16 st + 4g .. +3 of its query
   {
-    const float* f1p = f1e + (size_t)gpix * C + 4 * g;
+    const TI* f1p = f1e + (size_t)gpix * C + AM_EPC * g;
 #pragma unroll
     for (int st = 0; st < AM_MAXSTAGE; st++)
       a_all[st] = *reinterpret_cast<const f4*>(f1p + min(st * AM_CH, C - AM_CH));  // stages >= C/16 are never used
@@ -849,12 +868,12 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
   const Bilin obl = bilin_setup(cbase[2 * opix] * cscale, cbase[2 * opix + 1] * cscale, R);            \
   const float wnw = f32_value(obl.dy * obl.dx), wne = f32_value(obl.dy * (1.0f - obl.dx));             \
   const float wsw = f32_value((1.0f - obl.dy) * obl.dx), wse = f32_value((1.0f - obl.dy) * (1.0f - obl.dx)); \
-  float* out = oute + opix;   /* weights: ak:119-122 */
+  TO* out = oute + opix;   /* weights: ak:119-122 */
 
   if (!fits) {  // incoherent tile: per-query direct evaluation
     if (!ook) return;
     AM_OUT_ROLE
-    const float* f1 = f1e + (size_t)opix * C;
+    const TI* f1 = f1e + (size_t)opix * C;
     for (int o = og; o < RD * RD; o += 4) {
       const int ox = o / RD, oy = o % RD;
       float s4[4];
@@ -862,10 +881,18 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
         const int h2 = obl.y1 + oy + (t >> 1), w2 = obl.x1 + ox + (t & 1);
         float s = 0.f;
         if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
-          const float* f2 = f2b + ((size_t)h2 * W2 + w2) * C;
-          for (int c = 0; c < C; c += 4) {
-            const f4 u = *reinterpret_cast<const f4*>(f1 + c), v = *reinterpret_cast<const f4*>(f2 + c);
-            s = fmaf(u[0], v[0], s); s = fmaf(u[1], v[1], s); s = fmaf(u[2], v[2], s); s = fmaf(u[3], v[3], s);
+          const TI* f2 = f2b + ((size_t)h2 * W2 + w2) * C;
+          if constexpr (HALF_IN) {
+            for (int c = 0; c < C; c += 8) {
+              const h8 u = *reinterpret_cast<const h8*>(f1 + c), v = *reinterpret_cast<const h8*>(f2 + c);
+#pragma unroll
+              for (int k = 0; k < 8; k++) s = fmaf((float)u[k], (float)v[k], s);
+            }
+          } else {
+            for (int c = 0; c < C; c += 4) {
+              const f4 u = *reinterpret_cast<const f4*>(f1 + c), v = *reinterpret_cast<const f4*>(f2 + c);
+              s = fmaf(u[0], v[0], s); s = fmaf(u[1], v[1], s); s = fmaf(u[2], v[2], s); s = fmaf(u[3], v[3], s);
+            }
           }
         }
         s4[t] = s;
@@ -874,7 +901,7 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
       acc = acc + s4[1] * wsw;
       acc = acc + s4[2] * wne;
       acc = acc + s4[3] * wnw;
-      out[(size_t)o * H1W1] = acc;
+      am_store(out + (size_t)o * H1W1, acc);
     }
     return;
   }
@@ -886,7 +913,7 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
   // asm and retired with counted s_waitcnt vmcnt + raw s_barrier: hipcc would otherwise drain
   // every outstanding LDS-DMA (vmcnt(0)) in front of each LDS read and each __syncthreads().
   const int nk = (npos + 15) >> 4;
-  const int slot_floats = nk * (16 * AM_CH);
+  const int slot_floats = nk * 256;                  // 16 positions x 64 bytes per DMA instruction
   const int nstage = C / AM_CH;                      // <= AM_MAXSTAGE (checked by the launcher)
   const int cw = nk > wave ? (nk - wave + 3) >> 2 : 0;  // DMA instructions of this wave per stage
   int depth = min(nstage, AM_LDS_FLOATS / max(slot_floats, 1));
@@ -897,18 +924,18 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
   for (int it = 0; it < AM_MAXSLOT; it++) {
     const int P = min(16 * (wave + 4 * it) + (lane >> 2), max(npos - 1, 0));  // pad lanes re-read the last row
     const int yy = (int)(((float)P + 0.5f) * rbw), xx = P - yy * BW;  // exact: P < 1024, BW < 1024
-    soff[it] = ((by0 + yy) * W2 + (bx0 + xx)) * C + 4 * ((lane & 3) ^ ((lane >> 3) & 3));
+    soff[it] = ((by0 + yy) * W2 + (bx0 + xx)) * C + AM_EPC * ((lane & 3) ^ ((lane >> 3) & 3));
   }
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds);
   auto issue_stage = [&](int stage, int slot) {
-    const float* src = f2b + stage * AM_CH;
+    const TI* src = f2b + stage * AM_CH;
     const unsigned dst0 = lds_base + 4u * (unsigned)(slot * slot_floats);
 #pragma unroll
     for (int it = 0; it < AM_MAXSLOT; it++) {
       const int k = wave + 4 * it;
       if (k < nk) {  // wave-uniform
-        const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + 4u * (unsigned)(k * (16 * AM_CH)));
-        const float* gsrc = src + soff[it];
+        const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + 4u * (unsigned)(k * 256));
+        const TI* gsrc = src + soff[it];
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
@@ -936,7 +963,7 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
       const int pp = 16 * blk + row;
       const int py = (int)(((float)pp + 0.5f) * rsw), px = pp - py * sw;
       const int r0 = (pp < nposw) ? rbase + py * BW + px : 0;
-      boff[blk] = r0 * AM_CH + 4 * (g ^ ((r0 >> 1) & 3));
+      boff[blk] = r0 * 16 + 4 * (g ^ ((r0 >> 1) & 3));
     }
   }
   f4 acc[AM_MAXBLK];
@@ -980,11 +1007,18 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
           const f4 b1 = *reinterpret_cast<const f4*>(bs + boff[3 * grp + 1]);
           const f4 b2 = *reinterpret_cast<const f4*>(bs + boff[3 * grp + 2]);
           f4 c0 = acc[3 * grp], c1 = acc[3 * grp + 1], c2 = acc[3 * grp + 2];
+          if constexpr (HALF_IN) {  // lane group g holds k = 8g .. 8g+7 of both operands: one instruction per stage
+            const h8 ah = __builtin_bit_cast(h8, a);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(h8, b0), c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(h8, b1), c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(h8, b2), c2, 0, 0, 0);
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b2[e], c2, 0, 0, 0);
+            for (int e = 0; e < 4; e++) {
+              c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], c1, 0, 0, 0);
+              c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b2[e], c2, 0, 0, 0);
+            }
           }
           acc[3 * grp] = c0; acc[3 * grp + 1] = c1; acc[3 * grp + 2] = c2;
         }
@@ -1064,13 +1098,13 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
     if (!ook) return;
 #pragma unroll
     for (int m = 0; m < NOUT; m++)
-      if (og + 4 * m < RD * RD) out[(size_t)(og + 4 * m) * H1W1] = vacc[m];
+      if (og + 4 * m < RD * RD) am_store(out + (size_t)(og + 4 * m) * H1W1, vacc[m]);
   } else if (__all(inside)) {
     AMNOTE(11, 1);
     if (!ook) return;
     for (int ox = og; ox < RD; ox += 4) {
       const float* dp = dq + ry * osw + rx + ox;
-      float* op = out + (size_t)ox * RD * H1W1;
+      TO* op = out + (size_t)ox * RD * H1W1;
       float t0 = dp[0], t1 = dp[1];
 #pragma unroll
       for (int oy = 0; oy < RD; oy++) {
@@ -1080,7 +1114,7 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
         v = v + t1 * wsw;     // tap (oy  , ox+1)
         v = v + u0 * wne;     // tap (oy+1, ox  )
         v = v + u1 * wnw;     // tap (oy+1, ox+1)
-        op[(size_t)oy * H1W1] = v;
+        am_store(op + (size_t)oy * H1W1, v);
         t0 = u0; t1 = u1;
       }
     }
@@ -1091,7 +1125,7 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
       const int xa = rx + ox, xb = xa + 1;
       const bool ina = xa >= 0 && xa < osw, inb = xb >= 0 && xb < osw;
       const int xac = min(max(xa, 0), xmax), xbc = min(max(xb, 0), xmax);
-      float* op = out + (size_t)ox * RD * H1W1;
+      TO* op = out + (size_t)ox * RD * H1W1;
       float t0 = 0.f, t1 = 0.f;
 #pragma unroll
       for (int j = 0; j < NT; j++) {
@@ -1106,7 +1140,7 @@ __device__ __forceinline__ void altcorr_mfma_body(const float* __restrict__ f1e,
           v = v + t1 * wsw;
           v = v + u0 * wne;
           v = v + u1 * wnw;
-          op[(size_t)(j - 1) * H1W1] = v;
+          am_store(op + (size_t)(j - 1) * H1W1, v);
         }
         t0 = u0; t1 = u1;
       }
@@ -1128,11 +1162,11 @@ __device__ __forceinline__ unsigned am_virtual_id() {
 }
 
 // altcorr_forward (ak:27-142): grid (tiles, N, B)
-template <int R>
-__global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(const float* __restrict__ fmap1,
-                                                               const float* __restrict__ fmap2,
+template <int R, typename TI, typename TO>
+__global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(const TI* __restrict__ fmap1,
+                                                               const TI* __restrict__ fmap2,
                                                                const float* __restrict__ coords,
-                                                               float* __restrict__ corr, int N, int H1,
+                                                               TO* __restrict__ corr, int N, int H1,
                                                                int W1, int H2, int W2, int C) {
   constexpr int RD = 2 * R + 1;
   const unsigned v = am_virtual_id();
@@ -1140,7 +1174,7 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(co
   const unsigned e = v / gridDim.x;
   const int n = (int)(e % gridDim.y), b = (int)(e / gridDim.y);
   const size_t H1W1 = (size_t)H1 * W1;
-  altcorr_mfma_body<R>(fmap1 + (size_t)b * H1W1 * C, fmap2 + (size_t)b * H2 * W2 * C,
+  altcorr_mfma_body<R, TI, TO>(fmap1 + (size_t)b * H1W1 * C, fmap2 + (size_t)b * H2 * W2 * C,
                        coords + ((size_t)b * N + n) * H1W1 * 2, 1.0f,
                        corr + (((size_t)b * N + n) * RD * RD) * H1W1, tile, H1, W1, H2, W2, C);
 }
@@ -1150,9 +1184,9 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_forward_mfma(co
 // copies of the feature maps (`pyramid[i][:, jj]`).  grid (tiles, levels, E); output
 // [E, levels*(2r+1)^2, H, W] = torch.cat of the per-level results for one coordinate set.
 struct AltPyramid {
-  const float* level[4];  // [frames, H >> l, W >> l, C] fp32, channels last
+  const void* level[4];  // [frames, H >> l, W >> l, C] fp32 or fp16, channels last
 };
-template <int R>
+template <int R, typename TI>
 __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_pyramid_mfma(AltPyramid pyr,
                                                                const int64_t* __restrict__ ii,
                                                                const int64_t* __restrict__ jj,
@@ -1175,8 +1209,8 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_pyramid_mfma(Al
       for (int o = threadIdx.x >> 6; o < RD * RD; o += 4) oute[(size_t)o * H1W1 + qy * W1 + qx] = 0.f;
     return;
   }
-  const float* lp = lvl == 0 ? pyr.level[0] : (lvl == 1 ? pyr.level[1] : (lvl == 2 ? pyr.level[2] : pyr.level[3]));
-  altcorr_mfma_body<R>(pyr.level[0] + (size_t)fi * H1W1 * C, lp + (size_t)fj * H2 * W2 * C,
+  const TI* lp = static_cast<const TI*>(lvl == 0 ? pyr.level[0] : (lvl == 1 ? pyr.level[1] : (lvl == 2 ? pyr.level[2] : pyr.level[3])));
+  altcorr_mfma_body<R, TI, float>(static_cast<const TI*>(pyr.level[0]) + (size_t)fi * H1W1 * C, lp + (size_t)fj * H2 * W2 * C,
                        coords + (size_t)e * H1W1 * 2, 1.0f / (float)(1 << lvl), oute, tile, H1, W1, H2, W2, C);
 }
 
@@ -1200,15 +1234,29 @@ int launch_altcorr_forward(const void* f1, const void* f2, const float* coords, 
                            int N, int H1, int W1, int H2, int W2, int C, int r, int dtype,
                            hipStream_t s) {
   if (B > 65535 || N > 65535) return DROID_E_ARG;
-  if (dtype == DROID_F32 && (C % AM_CH) == 0 && C <= AM_CH * AM_MAXSTAGE && (r == 3 || r == 4) && (long)H2 * W2 * C < (1l << 30)) {
+  if (dtype == DROID_F32 && (C % AmIn<float>::CH) == 0 && C <= AmIn<float>::CH * AmIn<float>::MAXSTAGE && (r == 3 || r == 4) &&
+      (long)H2 * W2 * C < (1l << 30)) {
     const int tiles = ((W1 + AM_TX - 1) / AM_TX) * ((H1 + AM_TY - 1) / AM_TY);
     dim3 grid(tiles, N, B), block(256);
     if (r == 3)
-      hipLaunchKernelGGL((altcorr_forward_mfma<3>), grid, block, 0, s, static_cast<const float*>(f1),
+      hipLaunchKernelGGL((altcorr_forward_mfma<3, float, float>), grid, block, 0, s, static_cast<const float*>(f1),
                          static_cast<const float*>(f2), coords, static_cast<float*>(corr), N, H1, W1, H2, W2, C);
     else
-      hipLaunchKernelGGL((altcorr_forward_mfma<4>), grid, block, 0, s, static_cast<const float*>(f1),
+      hipLaunchKernelGGL((altcorr_forward_mfma<4, float, float>), grid, block, 0, s, static_cast<const float*>(f1),
                          static_cast<const float*>(f2), coords, static_cast<float*>(corr), N, H1, W1, H2, W2, C);
+    return 0;
+  }
+  // half maps (altcorr_kernel.cu:308 dispatches half): f16 matrix cores, fp32 accumulation, half output
+  if (dtype == DROID_F16 && (C % AmIn<__half>::CH) == 0 && C <= AmIn<__half>::CH * AmIn<__half>::MAXSTAGE && (r == 3 || r == 4) &&
+      (long)H2 * W2 * C < (1l << 30)) {
+    const int tiles = ((W1 + AM_TX - 1) / AM_TX) * ((H1 + AM_TY - 1) / AM_TY);
+    dim3 grid(tiles, N, B), block(256);
+    if (r == 3)
+      hipLaunchKernelGGL((altcorr_forward_mfma<3, __half, __half>), grid, block, 0, s, static_cast<const __half*>(f1),
+                         static_cast<const __half*>(f2), coords, static_cast<__half*>(corr), N, H1, W1, H2, W2, C);
+    else
+      hipLaunchKernelGGL((altcorr_forward_mfma<4, __half, __half>), grid, block, 0, s, static_cast<const __half*>(f1),
+                         static_cast<const __half*>(f2), coords, static_cast<__half*>(corr), N, H1, W1, H2, W2, C);
     return 0;
   }
   if (dtype == DROID_F32 && (C % ALT_CH) == 0 && (r == 3 || r == 4)) {
@@ -1232,20 +1280,27 @@ int launch_altcorr_forward(const void* f1, const void* f2, const float* coords, 
 
 // fused AltCorrBlock.corr_fn: see altcorr_pyramid_mfma.  Returns DROID_E_ARG for configurations the
 // matrix-core path does not cover (the caller then runs altcorr_forward per level).
-int launch_altcorr_pyramid_forward(const float* const* levels_dev, const int64_t* ii, const int64_t* jj,
+int launch_altcorr_pyramid_forward(const void* const* levels_dev, const int64_t* ii, const int64_t* jj,
                                    const float* coords, float* corr, int E, int frames, int H, int W, int C,
-                                   int r, int nlevels, hipStream_t s) {
-  if (nlevels < 1 || nlevels > 4 || (r != 3 && r != 4) || (C % AM_CH) != 0 || C > AM_CH * AM_MAXSTAGE) return DROID_E_ARG;
+                                   int r, int nlevels, int dtype, hipStream_t s) {
+  if (dtype != DROID_F32 && dtype != DROID_F16) return DROID_E_ARG;
+  const int ch = dtype == DROID_F16 ? AmIn<__half>::CH : AmIn<float>::CH;
+  if (nlevels < 1 || nlevels > 4 || (r != 3 && r != 4) || (C % ch) != 0 || C > 128) return DROID_E_ARG;
   if ((H >> (nlevels - 1)) < 1 || (W >> (nlevels - 1)) < 1 || (long)H * W * C >= (1l << 30)) return DROID_E_ARG;
   if ((long)E * nlevels > 65535) return DROID_E_ARG;
   AltPyramid pyr;
   for (int l = 0; l < 4; l++) pyr.level[l] = levels_dev[l < nlevels ? l : nlevels - 1];
   const int tiles = ((W + AM_TX - 1) / AM_TX) * ((H + AM_TY - 1) / AM_TY);
   dim3 grid(tiles, nlevels, E), block(256);
-  if (r == 3)
-    hipLaunchKernelGGL((altcorr_pyramid_mfma<3>), grid, block, 0, s, pyr, ii, jj, coords, corr, frames, H, W, C);
+  if (dtype == DROID_F16) {
+    if (r == 3)
+      hipLaunchKernelGGL((altcorr_pyramid_mfma<3, __half>), grid, block, 0, s, pyr, ii, jj, coords, corr, frames, H, W, C);
+    else
+      hipLaunchKernelGGL((altcorr_pyramid_mfma<4, __half>), grid, block, 0, s, pyr, ii, jj, coords, corr, frames, H, W, C);
+  } else if (r == 3)
+    hipLaunchKernelGGL((altcorr_pyramid_mfma<3, float>), grid, block, 0, s, pyr, ii, jj, coords, corr, frames, H, W, C);
   else
-    hipLaunchKernelGGL((altcorr_pyramid_mfma<4>), grid, block, 0, s, pyr, ii, jj, coords, corr, frames, H, W, C);
+    hipLaunchKernelGGL((altcorr_pyramid_mfma<4, float>), grid, block, 0, s, pyr, ii, jj, coords, corr, frames, H, W, C);
   return 0;
 }
 

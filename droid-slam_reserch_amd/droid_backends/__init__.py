@@ -395,9 +395,12 @@ def altcorr_forward(fmap1, fmap2, coords, radius):
 def altcorr_pyramid_forward(pyramid, coords, ii, jj, radius):
     """AltCorrBlock.corr_fn (droid_slam/modules/corr.py:105-125) in one launch, without the per-edge
     copies `pyramid[i][:, jj]`: pyramid = AltCorrBlock.pyramid (list of [1, frames, H>>l, W>>l, C]
-    or [frames, ...] float32 tensors), coords [E, H, W, 2] (or [1, E, H, W, 2]) float32 at level-0
-    scale, ii / jj [E] int64.  Returns [corr] with corr [E, levels*(2r+1)^2, H, W] =
-    torch.cat([altcorr_forward(pyramid[0][ii], pyramid[l][jj], coords / 2**l, r) for l], dim=1).
+    or [frames, ...] tensors), coords [E, H, W, 2] (or [1, E, H, W, 2]) float32 at level-0
+    scale, ii / jj [E] int64.  Returns [corr] with corr [E, levels*(2r+1)^2, H, W] float32 =
+    torch.cat([altcorr_forward(pyramid[0][ii].float(), pyramid[l][jj].float(), coords / 2**l, r) for l], dim=1).
+    The pyramid may be float32 or -- what the SLAM path holds, `video.fmaps` is half (depth_video.py:44,
+    factor_graph.py:260-261, modules/corr.py:97-104) -- float16: the half pyramid goes to the f16 matrix cores
+    as it is (no `.float()` copies; the result is the fp32 evaluation of the widened maps up to summation order).
     Not one of the reference's nine operators."""
     lib = _lib.load()
     levels = [p[0] if p.dim() == 5 else p for p in pyramid]
@@ -405,8 +408,8 @@ def altcorr_pyramid_forward(pyramid, coords, ii, jj, radius):
         coords = coords[0]
     for i, p in enumerate(levels):
         _check_input(p, f"pyramid[{i}]")
-        if p.dtype != torch.float32:
-            raise RuntimeError("altcorr_pyramid_forward: pyramid must be float32")
+        if p.dtype != levels[0].dtype or p.dtype not in (torch.float32, torch.float16):
+            raise RuntimeError("altcorr_pyramid_forward: pyramid levels must all be float32 or all float16")
     _check_input(coords, "coords")
     _check_input(ii, "ii")
     _check_input(jj, "jj")
@@ -423,9 +426,9 @@ def altcorr_pyramid_forward(pyramid, coords, ii, jj, radius):
     rd = 2 * r + 1
     corr = torch.empty((E, len(levels) * rd * rd, H, W), dtype=torch.float32, device=coords.device)
     ptrs = (ctypes.c_void_p * len(levels))(*[p.data_ptr() for p in levels])
-    _lib.check(lib.droid_altcorr_pyramid_forward(ptrs, ii.data_ptr(), jj.data_ptr(), coords.data_ptr(),
-                                                 corr.data_ptr(), E, int(frames), int(H), int(W), int(C), r,
-                                                 len(levels), _stream()), "altcorr_pyramid_forward")
+    fn = lib.droid_altcorr_pyramid_forward_f16 if levels[0].dtype == torch.float16 else lib.droid_altcorr_pyramid_forward
+    _lib.check(fn(ptrs, ii.data_ptr(), jj.data_ptr(), coords.data_ptr(), corr.data_ptr(), E, int(frames), int(H),
+                  int(W), int(C), r, len(levels), _stream()), "altcorr_pyramid_forward")
     return [corr]
 
 

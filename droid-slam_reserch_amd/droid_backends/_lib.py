@@ -17,6 +17,7 @@ SYMBOLS = [
     "droid_abi_version", "droid_last_error",
     "droid_corr_index_forward", "droid_corr_index_backward", "droid_corr_pyramid_forward",
     "droid_altcorr_forward", "droid_altcorr_backward", "droid_altcorr_pyramid_forward",
+    "droid_altcorr_pyramid_forward_f16",
     "droid_ba_workspace_bytes", "droid_ba", "droid_ba_prepare", "droid_ba_build", "droid_ba_build_packed",
     "droid_ba_packed_system", "droid_ba_unpack_system",
     "droid_ba_solve_update", "droid_ba_profile_iteration", "droid_ba_system", "droid_ba_status",
@@ -56,6 +57,7 @@ def load() -> ctypes.CDLL:
     lib.droid_altcorr_forward.argtypes = [vp, vp, vp, vp] + [c_int] * 9 + [vp]
     lib.droid_altcorr_backward.argtypes = [vp] * 6 + [c_int] * 8 + [vp]
     lib.droid_altcorr_pyramid_forward.argtypes = [ctypes.POINTER(vp), vp, vp, vp, vp] + [c_int] * 7 + [vp]
+    lib.droid_altcorr_pyramid_forward_f16.argtypes = [ctypes.POINTER(vp), vp, vp, vp, vp] + [c_int] * 7 + [vp]
     lib.droid_ba_workspace_bytes.argtypes = [c_int] * 7
     lib.droid_ba_workspace_bytes.restype = sz
     lib.droid_ba.argtypes = [vp] * 9 + [c_int] * 8 + [c_float, c_float, c_int, vp, vp, vp, sz, vp]

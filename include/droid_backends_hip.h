@@ -85,6 +85,19 @@ int droid_altcorr_pyramid_forward(const float *const *pyramid, const int64_t *ii
                                   const float *coords, float *corr, int E, int frames, int H, int W,
                                   int C, int radius, int levels, void *stream);
 
+/* The same operator for the pyramid the SLAM path actually holds: `AltCorrBlock(self.video.fmaps[None])`
+ * (factor_graph.py:260-261) is built from the HALF feature buffer (depth_video.py:44), `/ 4.0` and `avg_pool2d`
+ * stay in half (modules/corr.py:97-104), and `corr_fn` widens the gathered per-edge copies with `.float()`
+ * (:120) before the fp32 kernel.  This entry point takes that half pyramid as it is -- level l =
+ * [frames, H>>l, W>>l, C] f16 channels last -- and returns the fp32 tensor the reference's
+ * `altcorr_forward(fmap1.float(), fmap2.float(), ...)` calls return: products of two halves are exact in fp32 and
+ * the dot products are accumulated in fp32 on v_mfma_f32_16x16x32_f16, so only the summation order over channels
+ * differs (<= 1e-6 of the output scale; half subnormals are not flushed).  No `.float()` copies, half the feature
+ * bytes, 16x the matrix rate of the fp32 path.  C % 32 == 0, C <= 128; otherwise as above. */
+int droid_altcorr_pyramid_forward_f16(const void *const *pyramid, const int64_t *ii, const int64_t *jj,
+                                      const float *coords, float *corr, int E, int frames, int H, int W,
+                                      int C, int radius, int levels, void *stream);
+
 /* altcorr_backward (droid.cpp:205-217 -> altcorr_kernel.cu:322-355), fp32 only like the reference.
  * fmap1_grad/fmap2_grad must be zero-filled by the caller (atomic accumulation);
  * coords_grad is not written (the reference returns zeros). */

@@ -99,14 +99,18 @@ def test_cfg2_volume_lookup_48x64_four_levels_bit_exact(backends, oracle, cfg2_v
     assert fused.dtype == tdt and torch.equal(fused, cat[0])
 
 
-def _alt_pyramid(torch, fmaps_f16):
-    """AltCorrBlock.__init__ (modules/corr.py:92-104): /4, channels-last levels by avg_pool2d."""
+def _alt_pyramid(torch, fmaps_f16, half=False):
+    """AltCorrBlock.__init__ (modules/corr.py:92-104): /4, channels-last levels by avg_pool2d.  `half`: the
+    arithmetic of the SLAM path -- `video.fmaps` is torch.half (depth_video.py:44), so `/ 4.0` and the pooling
+    stay in half and the pyramid IS half (factor_graph.py:260-261); otherwise a float32 pyramid (training)."""
     import torch.nn.functional as F
-    x = torch.from_numpy(fmaps_f16).cuda().float() / 4.0
+    x = torch.from_numpy(fmaps_f16).cuda()
+    x = (x if half else x.float()) / 4.0
     pyr = []
     for _ in range(4):
         pyr.append(x.permute(0, 2, 3, 1).contiguous()[None])    # [1,frames,h,w,C]
         x = F.avg_pool2d(x, 2, stride=2)
+    assert pyr[0].dtype == (torch.float16 if half else torch.float32)
     return pyr
 
 
@@ -130,6 +134,40 @@ def _check_alt_levels(backends, oracle, torch, pyr, coords, i1, i2, r, tag):
     assert torch.equal(fused, torch.cat(parts, dim=1))
 
 
+def _check_alt_half_pyramid(backends, oracle, torch, pyr_h, coords, i1, i2, r, tag):
+    """The half pyramid of the SLAM path through the f16 matrix-core entry point: against the fp64 oracle evaluated
+    on the SAME half values (what `corr_fn`'s `.float()` copies hold, modules/corr.py:120) <= 1e-5 of the output
+    scale, against this library's fp32 kernel on the widened maps <= 2e-6 (only the summation order differs:
+    products of two halves are exact in fp32), and `altcorr_forward(half, half)` (altcorr_kernel.cu:308) == that
+    fp32 result rounded to half within one half ulp."""
+    E, H, W = coords.shape[:3]
+    assert pyr_h[0].dtype == torch.float16
+    fused, = backends.altcorr_pyramid_forward(pyr_h, coords, i1, i2, r)
+    assert fused.dtype == torch.float32 and tuple(fused.shape) == (E, 4 * (2 * r + 1) ** 2, H, W)
+    got = fused.cpu().numpy()
+    assert np.isfinite(got).all()
+    pyr_f = [p.float() for p in pyr_h]
+    wide, = backends.altcorr_pyramid_forward(pyr_f, coords, i1, i2, r)
+    n = (2 * r + 1) ** 2
+    for l in range(4):
+        f1 = pyr_h[0][0][i1].contiguous()
+        f2 = pyr_h[l][0][i2].contiguous()
+        cl = (coords / 2 ** l).reshape(E, 1, H, W, 2).contiguous()
+        ref = oracle.altcorr_forward(f1.float().cpu().numpy(), f2.float().cpu().numpy(), cl.cpu().numpy(), r,
+                                     acc_dtype=np.float64)[:, 0]
+        scale = np.abs(ref).max()
+        e64 = np.abs(got[:, l * n:(l + 1) * n] - ref).max() / scale
+        e32 = float((fused[:, l * n:(l + 1) * n] - wide[:, l * n:(l + 1) * n]).abs().max()) / scale
+        print(f"[{tag}] level {l}: f16-MFMA vs fp64 oracle {e64:.2e}, vs fp32 kernel on widened maps {e32:.2e} "
+              f"(scale {scale:.2f})")
+        assert e64 < 1e-5 and e32 < 2e-6, (tag, l, e64, e32)
+        out_h, = backends.altcorr_forward(f1, f2, cl, r)          # half in, half out
+        assert out_h.dtype == torch.float16
+        d = (out_h[:, 0].float() - fused[:, l * n:(l + 1) * n]).abs()
+        ulp = torch.clamp(fused[:, l * n:(l + 1) * n].abs(), min=2.0 ** -14) * 2.0 ** -10
+        assert bool((d <= ulp).all()), (tag, l, float((d / ulp).max()))
+
+
 def test_cfg3_altcorr_48x64_c128_r3(backends, oracle, synth):
     torch = _torch()
     prob = synth.make_config("cfg3")
@@ -145,6 +183,8 @@ def test_cfg3_altcorr_48x64_c128_r3(backends, oracle, synth):
     ii = torch.from_numpy(prob.ii[sel]).cuda()
     jj = torch.from_numpy(prob.jj[sel]).cuda()
     _check_alt_levels(backends, oracle, torch, pyr, torch.from_numpy(c).cuda(), ii, jj, 3, "cfg3 48x64 C128 r3")
+    _check_alt_half_pyramid(backends, oracle, torch, _alt_pyramid(torch, fmaps, half=True), torch.from_numpy(c).cuda(),
+                            ii, jj, 3, "cfg3 48x64 C128 r3 half pyramid")
 
 
 def test_cfg5_altcorr_96x128_r4_stereo_indexing(backends, oracle, synth):
@@ -165,6 +205,34 @@ def test_cfg5_altcorr_96x128_r4_stereo_indexing(backends, oracle, synth):
     pyr = _alt_pyramid(torch, fmaps)
     _check_alt_levels(backends, oracle, torch, pyr, torch.from_numpy(coords[sel].copy()).cuda(), i1, i2, 4,
                       "cfg5 96x128 C128 r4")
+    _check_alt_half_pyramid(backends, oracle, torch, _alt_pyramid(torch, fmaps, half=True),
+                            torch.from_numpy(coords[sel].copy()).cuda(), i1, i2, 4, "cfg5 96x128 C128 r4 half pyramid")
+
+
+def test_altcorr_half_subnormal_inputs_are_not_flushed(backends, oracle):
+    """fp16 subnormals (|x| < 6.1e-5) on the f16 matrix cores: the products must come through like in the
+    reference's fp32 evaluation of the widened maps.  fmap1 carries subnormal halves (k * 2^-24), fmap2 values
+    around 2^10, so every dot product is O(1) if and only if the subnormal operands are kept."""
+    torch = _torch()
+    rng = np.random.default_rng(91)
+    B, H, W, C, r = 1, 8, 16, 64, 3
+    f1 = (rng.integers(1, 1000, (B, H, W, C)) * 2.0 ** -24).astype(np.float16)
+    assert (np.abs(f1.astype(np.float64)) < 6.104e-5).all() and (f1 != 0).all()
+    f2 = (rng.choice([-1.0, 1.0], (B, H, W, C)) * rng.integers(512, 2048, (B, H, W, C))).astype(np.float16)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    coords = np.stack([xx + 0.25, yy + 0.5], -1)[None, None].astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out, = backends.altcorr_forward(t(f1), t(f2), t(coords), r)
+    ref = oracle.altcorr_forward(f1.astype(np.float32), f2.astype(np.float32), coords, r, acc_dtype=np.float64)
+    got = out.float().cpu().numpy()
+    scale = np.abs(ref).max()
+    assert scale > 0.05
+    assert np.abs(got - ref).max() / scale < 2e-3          # half output: a half ulp of the scale
+    # and through the fp32-output entry point (two single-level pyramids: f1 is level 0 of frame 0, f2 of frame 1)
+    pyr = [torch.cat([t(f1), t(f2)], 0)]
+    fused, = backends.altcorr_pyramid_forward(pyr, t(coords[0]), torch.tensor([0], device="cuda"),
+                                              torch.tensor([1], device="cuda"), r)
+    assert np.abs(fused.cpu().numpy() - ref[:, 0]).max() / scale < 1e-5
 
 
 @pytest.mark.parametrize("lvl", [0, 2])
