@@ -1214,6 +1214,299 @@ __global__ __launch_bounds__(256, AmCfg<R>::MIN_WG) void altcorr_pyramid_mfma(Al
                        coords + (size_t)e * H1W1 * 2, 1.0f / (float)(1 << lvl), oute, tile, H1, W1, H2, W2, C);
 }
 
+// ---- alt-corr on the f16 matrix cores: one autonomous wave per 16 queries, all pyramid levels --------------------
+// The half pyramid of the SLAM path (modules/corr.py:92-104 on video.fmaps, a torch.half buffer).  With
+// v_mfma_f32_16x16x32_f16 the box GEMM costs 1/16 of its fp32 time, and what bounded the workgroup-cooperative
+// kernel above -- four barriers per K stage, a staging plan for the whole workgroup, phases that wait for each
+// other -- becomes the whole cost (stamps: 20 k cycles per workgroup, 2 k of them MFMA).  So here every wave is its
+// own workgroup and never meets a barrier:
+//   * 16 queries (a 4x4 sub-tile) against the bounding box of THEIR windows, for all levels in turn: the level-0
+//     rows of the queries (fmap1 is level 0 at every level, corr.py:113) are loaded once as MFMA B operands;
+//   * fmap2 positions are the A operand.  The operand layout wants lane (row = l & 15, k-group = l >> 4), which read
+//     straight from memory runs at 14 B/clk/CU (tools/micro/ldmap.hip: the four lanes of a 64-byte run are 16 lanes
+//     apart, every lane its own request); so blocks of 16 positions x 128 channels (4 KB) arrive by LDS-DMA with
+//     four ADJACENT lanes per 64-byte run (47 B/clk/CU) into a private ring of three slots, XOR-swizzled on the
+//     source side, and leave it as ds_read_b128 operands -- K is complete per block, so a block is four MFMAs
+//     into its own accumulator;
+//   * accumulators stay in registers until the last block, then go to LDS as D[query][position] (the lane holds
+//     four consecutive positions of ONE query: one ds_write_b128 per block) over the ring's memory, and the wave
+//     combines its own 16 queries: lane (query, column group) walks output columns, two FMAs per tap pair;
+//   * LDS-DMA completion is counted per block with s_waitcnt vmcnt (loads, DMAs and the previous level's output
+//     stores retire in order); LDS accesses of one wave execute in order, so no other synchronisation exists.
+// 15.6 KB of LDS per wave: ten waves per CU hide each other's latencies.
+// min / max over the 16 lanes of a DPP row in four VALU instructions (no LDS round trips: __shfl_xor goes through
+// ds_bpermute, ~100 cycles each, 16 of them per level): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ int row_min16(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+  return v;
+}
+__device__ __forceinline__ int row_max16(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+  return v;
+}
+template <int R> struct AwCfg {
+  static constexpr int MAXBLK = (R <= 3) ? 15 : 20;   // 16-position blocks per wave box (r=4 windows are 10x10)
+  static constexpr int CP = 16 * MAXBLK + 4;          // D pitch in floats (== 4 mod 32)
+  static constexpr int LDS_FLOATS = 16 * CP;
+  static constexpr int NRING = 3;                     // 4-KB block slots of the staging ring (inside the D buffer)
+};
+struct AwArgs {
+  const __half* f1;        // level-0 maps of the query frames [frames | B, H1, W1, C]
+  const __half* f2[4];     // per level [frames | B, H2, W2, C]
+  const int64_t* ii;       // frame of the queries per edge; null: the batch index (altcorr_forward)
+  const int64_t* jj;
+  const float* coords;     // [E | B, N, H1, W1, 2]
+  void* corr;              // [E | B, N, levels, (2r+1)^2, H1, W1]
+  int frames, N, H1, W1, C, nlevels;
+  int H2[4], W2[4];
+  float cscale[4];
+};
+
+template <int R, int NST, typename TO>
+__global__ __launch_bounds__(64) void altcorr_wave_f16(const AwArgs a) {
+  constexpr int RD = 2 * R + 1, NT = RD + 1;
+  constexpr int MAXBLK = AwCfg<R>::MAXBLK, CP = AwCfg<R>::CP, NRING = AwCfg<R>::NRING;
+  static_assert(NRING * 1024 <= AwCfg<R>::LDS_FLOATS, "ring inside the D buffer");
+  __shared__ __attribute__((aligned(16))) float lds[AwCfg<R>::LDS_FLOATS];
+  const int lane = threadIdx.x;
+  const int q = lane & 15, g = lane >> 4;
+  const int C = a.C, H1 = a.H1, W1 = a.W1, H1W1 = H1 * W1;
+  // XCD-aware order (am_virtual_id): the sub-tiles of one edge share an L2
+  const unsigned v = am_virtual_id();
+  const int tiles_x = (W1 + 3) >> 2;
+  const int tile = (int)(v % gridDim.x);
+  const unsigned bn = v / gridDim.x;
+  const int n = (int)(bn % gridDim.y), e = (int)(bn / gridDim.y);
+  const int qx = (tile % tiles_x) * 4 + (q & 3), qy = (tile / tiles_x) * 4 + (q >> 2);
+  const bool ok = qx < W1 && qy < H1;
+  const int pix = ok ? qy * W1 + qx : 0;
+  int64_t fi = e, fj = e;
+  if (a.ii) { fi = a.ii[e]; fj = a.jj[e]; }
+  const bool frames_ok = fi >= 0 && fi < a.frames && fj >= 0 && fj < a.frames;
+  TO* const out0 = static_cast<TO*>(a.corr) + ((size_t)e * a.N + n) * a.nlevels * (RD * RD) * (size_t)H1W1 + pix;
+  if (!frames_ok) {  // contract violation: zeros
+    if (ok)
+      for (int o = g; o < a.nlevels * RD * RD; o += 4) am_store(out0 + (size_t)o * H1W1, 0.f);
+    return;
+  }
+  const float2 gc = *reinterpret_cast<const float2*>(a.coords + (((size_t)e * a.N + n) * H1W1 + pix) * 2);
+  // B operands: this query's level-0 row, k-group g of k-step s = channels 32 s + 8 g .. + 7
+  AMSTAMP(0);
+  f4 fq[NST];   // NST = C / 32 k-steps
+  {
+    const __half* f1p = a.f1 + ((size_t)fi * H1W1 + pix) * C + 8 * g;
+#pragma unroll
+    for (int s = 0; s < NST; s++) fq[s] = *reinterpret_cast<const f4*>(f1p + 32 * s);
+  }
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds);
+  // A-operand address inside a ring slot: k-step image s = [16 positions][64 B], slot c of position i holds chunk
+  // c ^ ((i >> 1) & 3) (swizzled on the source side): conflict-free ds_read_b128
+  const int aoff = q * 16 + 4 * (g ^ ((q >> 1) & 3));                 // floats
+  // DMA role: lane -> position lane >> 2 of the block, 16-byte slot lane & 3 of its 64-byte k-step run
+  const int dpos = lane >> 2;
+  const int dchunk = 8 * ((lane & 3) ^ ((lane >> 3) & 3));            // halves
+#pragma unroll
+  for (int s = 0; s < NST; s++) asm volatile("" : "+v"(fq[s]));       // retire the operand loads before any LDS-DMA
+  AMSTAMP(1);
+
+  for (int lvl = 0; lvl < a.nlevels; lvl++) {
+    const int H2 = a.H2[lvl], W2 = a.W2[lvl];
+    const __half* f2b = a.f2[lvl] + (size_t)fj * H2 * W2 * C;
+    TO* out = out0 + (size_t)lvl * (RD * RD) * H1W1;
+    const Bilin bl = bilin_setup(gc.x * a.cscale[lvl], gc.y * a.cscale[lvl], R);
+    const float wnw = f32_value(bl.dy * bl.dx), wne = f32_value(bl.dy * (1.0f - bl.dx));      // ak:119-122
+    const float wsw = f32_value((1.0f - bl.dy) * bl.dx), wse = f32_value((1.0f - bl.dy) * (1.0f - bl.dx));
+    const bool hit = ok && bl.x1 + NT > 0 && bl.x1 < W2 && bl.y1 + NT > 0 && bl.y1 < H2;
+    const int big = 0x3fffffff;
+    const int x0 = __builtin_amdgcn_readfirstlane(max(row_min16(hit ? bl.x1 : big), 0));
+    const int y0 = __builtin_amdgcn_readfirstlane(max(row_min16(hit ? bl.y1 : big), 0));
+    const int x1 = __builtin_amdgcn_readfirstlane(min(row_max16(hit ? bl.x1 + NT : -big), W2));
+    const int y1 = __builtin_amdgcn_readfirstlane(min(row_max16(hit ? bl.y1 + NT : -big), H2));
+    const int sw = max(x1 - x0, 0), sh = max(y1 - y0, 0);
+    const int nposw = sw * sh;
+    const int nblk = (nposw + 15) >> 4;    // wave-uniform
+    if (nposw > 16 * MAXBLK) {             // incoherent coordinates: per-query direct evaluation
+      if (ok) {
+        const __half* f1 = a.f1 + ((size_t)fi * H1W1 + pix) * C;
+        for (int o = g; o < RD * RD; o += 4) {
+          const int ox = o / RD, oy = o % RD;
+          float s4[4];
+          for (int t = 0; t < 4; t++) {
+            const int h2 = bl.y1 + oy + (t >> 1), w2 = bl.x1 + ox + (t & 1);
+            float sacc = 0.f;
+            if (h2 >= 0 && h2 < H2 && w2 >= 0 && w2 < W2) {
+              const __half* f2 = f2b + ((size_t)h2 * W2 + w2) * C;
+              for (int c = 0; c < C; c += 8) {
+                const h8 u = *reinterpret_cast<const h8*>(f1 + c), w = *reinterpret_cast<const h8*>(f2 + c);
+#pragma unroll
+                for (int k = 0; k < 8; k++) sacc = fmaf((float)u[k], (float)w[k], sacc);
+              }
+            }
+            s4[t] = sacc;
+          }
+          float acc = s4[0] * wse;
+          acc = fmaf(s4[1], wsw, acc);
+          acc = fmaf(s4[2], wne, acc);
+          acc = fmaf(s4[3], wnw, acc);
+          am_store(out + (size_t)o * H1W1, acc);
+        }
+      }
+      continue;
+    }
+    // ---- box GEMM: D[position][query], block by block through the ring
+    const float rsw = 1.0f / (float)max(sw, 1);
+    // NST LDS-DMA instructions per block: the k-step images of block blk into slot blk % NRING.  One position decode
+    // and one 32-bit byte offset per lane and block (scalar base, the level's map is < 2 GB); the k-step moves by the
+    // instruction's immediate offset, which applies to the global address AND to the LDS destination
+    // (tools/micro/glds_off.hip), so M0 = image base - 64 s.
+    auto issue_block = [&](int blk) {
+      const int P = min(16 * blk + dpos, max(nposw - 1, 0));             // pad lanes re-read the last position
+      const int yy = (int)(((float)P + 0.5f) * rsw), xx = P - yy * sw;   // exact: P < 1024
+      const unsigned voff = 2u * (unsigned)(((y0 + yy) * W2 + (x0 + xx)) * C + dchunk);
+      const unsigned m0 = lds_base + 4096u * (unsigned)(blk % NRING);
+      unsigned keep;
+      if constexpr (NST == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_add_u32 m0, %3, 960\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:64\n\t"
+                     "s_add_u32 m0, %3, 1920\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:128\n\t"
+                     "s_add_u32 m0, %3, 2880\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:192\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(f2b), "s"(m0) : "memory", "scc");
+      else if constexpr (NST == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_add_u32 m0, %3, 960\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:64\n\t"
+                     "s_add_u32 m0, %3, 1920\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:128\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(f2b), "s"(m0) : "memory", "scc");
+      else if constexpr (NST == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "s_add_u32 m0, %3, 960\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:64\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(f2b), "s"(m0) : "memory", "scc");
+      else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(f2b), "s"(m0) : "memory", "scc");
+    };
+    f4 acc[MAXBLK];
+#pragma unroll
+    for (int blk = 0; blk < MAXBLK; blk++) acc[blk] = f4{0.f, 0.f, 0.f, 0.f};
+    // the combine of the previous level has read the D buffer (LDS executes a wave's accesses in order, and its
+    // results were consumed by the stores issued above): the ring may be refilled
+    AMSTAMP(2 + 7 * lvl);
+    AMNOTE(8 + 7 * lvl, nblk);
+    static_assert(NRING == 3, "the wait ladder below assumes two younger blocks at most");
+#pragma unroll
+    for (int d = 0; d < NRING; d++)
+      if (d < nblk) issue_block(d);
+    AMSTAMP(3 + 7 * lvl);
+#pragma unroll
+    for (int blk = 0; blk < MAXBLK; blk++) {
+      if (blk < nblk) {   // wave-uniform
+        // blocks younger than blk still in flight: min(NRING-1, nblk-1-blk), NST DMAs each
+        if (blk + 2 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST) : "memory");
+        else if (blk + 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (blk == 0) AMSTAMP(4 + 7 * lvl);
+        const float* slot = lds + 1024 * (blk % NRING) + aoff;
+        f4 pa[NST];
+#pragma unroll
+        for (int s = 0; s < NST; s++) pa[s] = *reinterpret_cast<const f4*>(slot + 256 * s);
+        f4 c = acc[blk];
+#pragma unroll
+        for (int s = 0; s < NST; s++)
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, pa[s]), __builtin_bit_cast(h8, fq[s]), c, 0, 0, 0);
+        acc[blk] = c;
+        if (blk + NRING < nblk) {           // refill this block's slot: its operand reads have returned
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          issue_block(blk + NRING);
+        }
+      }
+    }
+    // ---- D -> LDS (over the ring: every block has been read): lane holds positions 16 blk + 4 g .. + 3 of query q
+    AMSTAMP(5 + 7 * lvl);
+    __builtin_amdgcn_wave_barrier();
+    {
+      float* dl = lds + q * CP + 4 * g;
+#pragma unroll
+      for (int blk = 0; blk < MAXBLK; blk++)
+        if (blk < nblk) *reinterpret_cast<f4*>(dl + 16 * blk) = acc[blk];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    AMSTAMP(6 + 7 * lvl);
+    // ---- bilinear combine of the wave's own 16 queries: lane (query q, column group g) walks output columns
+    const int rx = bl.x1 - x0, ry = bl.y1 - y0;     // window origin inside the box
+    const float* dq = lds + q * CP;
+    const bool inside = !ok || (rx >= 0 && ry >= 0 && rx + NT <= sw && ry + NT <= sh);
+    if (__all(inside)) {
+      if (ok) {
+        for (int ox = g; ox < RD; ox += 4) {
+          const float* dp = dq + ry * sw + rx + ox;
+          TO* op = out + (size_t)ox * RD * H1W1;
+          float t0 = dp[0], t1 = dp[1];
+#pragma unroll
+          for (int oy = 0; oy < RD; oy++) {
+            dp += sw;
+            const float u0 = dp[0], u1 = dp[1];
+            float vv = t0 * wse;            // tap (oy  , ox  )
+            vv = fmaf(t1, wsw, vv);         // tap (oy  , ox+1)
+            vv = fmaf(u0, wne, vv);         // tap (oy+1, ox  )
+            vv = fmaf(u1, wnw, vv);         // tap (oy+1, ox+1)
+            am_store(op + (size_t)oy * H1W1, vv);
+            t0 = u0; t1 = u1;
+          }
+        }
+      }
+    } else if (ok) {
+      const int xmax = max(sw - 1, 0), ymax = max(sh - 1, 0);
+      for (int ox = g; ox < RD; ox += 4) {
+        const int xa = rx + ox, xb = xa + 1;
+        const bool ina = xa >= 0 && xa < sw, inb = xb >= 0 && xb < sw;
+        const int xac = min(max(xa, 0), xmax), xbc = min(max(xb, 0), xmax);
+        TO* op = out + (size_t)ox * RD * H1W1;
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+          const int yy = ry + j;
+          const bool iny = yy >= 0 && yy < sh;
+          const float* dp = dq + min(max(yy, 0), ymax) * sw;
+          float u0 = dp[xac], u1 = dp[xbc];
+          u0 = (iny && ina) ? u0 : 0.f;
+          u1 = (iny && inb) ? u1 : 0.f;
+          if (j > 0) {
+            float vv = t0 * wse;
+            vv = fmaf(t1, wsw, vv);
+            vv = fmaf(u0, wne, vv);
+            vv = fmaf(u1, wnw, vv);
+            am_store(op + (size_t)(j - 1) * H1W1, vv);
+          }
+          t0 = u0; t1 = u1;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    AMSTAMP(7 + 7 * lvl);
+  }
+}
+
+template <typename TO>
+static int launch_altcorr_wave_f16(const AwArgs& a, int r, int units, hipStream_t s) {
+  const int tiles = ((a.W1 + 3) / 4) * ((a.H1 + 3) / 4);
+  dim3 grid(tiles, a.N, units), block(64);
+#define AW_LAUNCH(RR, NN) hipLaunchKernelGGL((altcorr_wave_f16<RR, NN, TO>), grid, block, 0, s, a)
+  const int nst = a.C / 32;
+  if (r == 3) {
+    if (nst == 4) AW_LAUNCH(3, 4); else if (nst == 3) AW_LAUNCH(3, 3); else if (nst == 2) AW_LAUNCH(3, 2); else AW_LAUNCH(3, 1);
+  } else {
+    if (nst == 4) AW_LAUNCH(4, 4); else if (nst == 3) AW_LAUNCH(4, 3); else if (nst == 2) AW_LAUNCH(4, 2); else AW_LAUNCH(4, 1);
+  }
+#undef AW_LAUNCH
+  return 0;
+}
+
 #ifdef AM_STAMPS
 extern "C" int droid_debug_am_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_am_stamps), sizeof(unsigned long long) * 768 * 4 * 32);
@@ -1247,6 +1540,16 @@ int launch_altcorr_forward(const void* f1, const void* f2, const float* coords, 
     return 0;
   }
   // half maps (altcorr_kernel.cu:308 dispatches half): f16 matrix cores, fp32 accumulation, half output
+  if (dtype == DROID_F16 && (C % 32) == 0 && C <= 128 && (r == 3 || r == 4) && (long)H2 * W2 * C < (1l << 30) &&
+      (long)H1 * W1 * C < (1l << 30) && !getenv("DROID_ALTCORR_F16_WG")) {
+    AwArgs a{};
+    a.f1 = static_cast<const __half*>(f1);
+    a.f2[0] = static_cast<const __half*>(f2);
+    a.coords = coords; a.corr = corr;
+    a.frames = B; a.N = N; a.H1 = H1; a.W1 = W1; a.C = C; a.nlevels = 1;
+    a.H2[0] = H2; a.W2[0] = W2; a.cscale[0] = 1.0f;
+    return launch_altcorr_wave_f16<__half>(a, r, B, s);
+  }
   if (dtype == DROID_F16 && (C % AmIn<__half>::CH) == 0 && C <= AmIn<__half>::CH * AmIn<__half>::MAXSTAGE && (r == 3 || r == 4) &&
       (long)H2 * W2 * C < (1l << 30)) {
     const int tiles = ((W1 + AM_TX - 1) / AM_TX) * ((H1 + AM_TY - 1) / AM_TY);
@@ -1292,6 +1595,17 @@ int launch_altcorr_pyramid_forward(const void* const* levels_dev, const int64_t*
   for (int l = 0; l < 4; l++) pyr.level[l] = levels_dev[l < nlevels ? l : nlevels - 1];
   const int tiles = ((W + AM_TX - 1) / AM_TX) * ((H + AM_TY - 1) / AM_TY);
   dim3 grid(tiles, nlevels, E), block(256);
+  if (dtype == DROID_F16 && !getenv("DROID_ALTCORR_F16_WG")) {
+    AwArgs a{};
+    a.f1 = static_cast<const __half*>(levels_dev[0]);
+    for (int l = 0; l < nlevels; l++) {
+      a.f2[l] = static_cast<const __half*>(levels_dev[l]);
+      a.H2[l] = H >> l; a.W2[l] = W >> l; a.cscale[l] = 1.0f / (float)(1 << l);
+    }
+    a.ii = ii; a.jj = jj; a.coords = coords; a.corr = corr;
+    a.frames = frames; a.N = 1; a.H1 = H; a.W1 = W; a.C = C; a.nlevels = nlevels;
+    return launch_altcorr_wave_f16<float>(a, r, E, s);
+  }
   if (dtype == DROID_F16) {
     if (r == 3)
       hipLaunchKernelGGL((altcorr_pyramid_mfma<3, __half>), grid, block, 0, s, pyr, ii, jj, coords, corr, frames, H, W, C);
