@@ -20,6 +20,11 @@ N > 1 : BASELINE.json configs[3]: 256 keyframes / 8000 edges IN TOTAL (--edges-t
         iterations/s of the 8000-edge graph is config.raw_iters_per_sec.  `extra.weak_scaling` is the second
         figure: 2000 edges PER GPU (2000*N in total) on the same 256 keyframes.
 
+Launching: with --gpus N > 1 and no WORLD_SIZE in the environment this process starts the N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N` on 127.0.0.1, like the reference's `mp.spawn`, train.py:184-186)
+BEFORE anything touches HIP, stays GPU-free and relays rank 0's JSON line; under a launcher (WORLD_SIZE set) it is
+one of the ranks, and a WORLD_SIZE that differs from --gpus is an error.
+
 Rank 0 prints ONE JSON line (see the keys below); everything else goes to stderr.
 """
 from __future__ import annotations
@@ -57,7 +62,58 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-corr", action="store_true")
     ap.add_argument("--corr-edges", type=int, default=256, help="edges per corr-lookup batch")
+    ap.add_argument("--stub-backend", action="store_true",
+                    help="plumbing test without a GPU (tests/test_bench_launch.py): CPU tensors, gloo, a compute backend "
+                         "that only exercises the phase order and the collective; the line is marked invalid")
     return ap.parse_args()
+
+
+class _StubBackend:
+    """No arithmetic: every rank contributes rank + 1 to a tiny 'packed system' so that the all-reduce of
+    ShardedBA.run is observable in the result.  Only for --stub-backend."""
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.reduced = None
+
+    def prepare(self, p, t0, t1, own, motion_only):
+        self.packed = torch.zeros(8, dtype=torch.float64)
+        self.dx = torch.zeros((t1 - t0, 6), dtype=torch.float32)
+        self.M = int(p.eta.shape[0])
+
+    def build_packed(self, p, motion_only):
+        self.packed.fill_(float(self.rank + 1))
+        return self.packed
+
+    def build(self, p, motion_only):          # world size 1: no collective
+        self.reduced = float(self.rank + 1)
+        return self.packed
+
+    def unpack(self, motion_only):
+        self.reduced = float(self.packed[0])
+
+    def solve_update(self, p, lm, ep, motion_only):
+        return self.dx
+
+    def status(self):
+        return 0, self.M
+
+
+def spawn_ranks(args):
+    """Parent of a multi-GPU run: start one rank per GPU and relay their output.  No HIP call happens in this process
+    (importing torch does not initialise the runtime)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("spawning", args.gpus, "ranks:", " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def to_dev(a, dev):
@@ -82,17 +138,20 @@ def bench_ba(args, rank, world, dev, N, E, H=48, W=64, stereo=False, lm=1e-5, ep
         weights=to_dev(sh["weights"], dev), eta=to_dev(sh["eta"], dev), ii=to_dev(sh["ii"], dev),
         jj=to_dev(sh["jj"], dev))
     poses0, disps0 = p.poses.clone(), p.disps.clone()
-    solver = ba_driver.ShardedBA()
+    solver = ba_driver.ShardedBA(backend=_StubBackend(rank)) if args.stub_backend else ba_driver.ShardedBA()
+    on_gpu = dev.type == "cuda"
 
     def reset():
         p.poses.copy_(poses0)
         p.disps.copy_(disps0)
 
     def barrier():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     if args.warmup > 0:
         solver.run(p, prob.t0, prob.t1, args.warmup, prob.lm, prob.ep, own=sh["own"])
@@ -112,6 +171,8 @@ def bench_ba(args, rank, world, dev, N, E, H=48, W=64, stereo=False, lm=1e-5, ep
 
     info = dict(N=N, E=E, E_local=int(p.ii.shape[0]), M_local=int(p.eta.shape[0]), HW=H * W, P=prob.t1 - prob.t0,
                 chol_failed=bool(st & 4), steps=steps)
+    if args.stub_backend:
+        info["stub_allreduce_sum"] = solver.backend.reduced
     if not profile:
         return dt, {}, info, prob
     # per-stage durations: HIP events on the launch stream, averaged over 5 iterations
@@ -136,7 +197,7 @@ def bench_ba(args, rank, world, dev, N, E, H=48, W=64, stereo=False, lm=1e-5, ep
 
 
 def bench_corr(args, rank, world, dev, prob):
-    """Volume lookup (fp16, 4 levels, r=3) and alt-corr (fp32, 4 levels) on `corr_edges` edges."""
+    """Volume lookup (fp16, 4 levels, r=3) and alt-corr (half pyramid of the SLAM path; float32 pyramid) on `corr_edges` edges."""
     import torch.nn.functional as F
     import droid_backends as db
     from droid_backends import synth
@@ -192,39 +253,65 @@ def bench_corr(args, rank, world, dev, prob):
     out["volume_fp16"]["corrblock_call_ms"] = ms_call
     out["volume_fp16"]["corr_pyramid_forward_ms"] = ms_fused
     out["volume_fp16"]["corr_pyramid_forward_gpix_per_s"] = pix / ms_fused / 1e6
-    # alt-corr: channels-last fp32 pyramid of pooled fmaps (modules/corr.py:92-125)
+    # alt-corr.  What the SLAM path holds (update_lowmem, factor_graph.py:260-261): AltCorrBlock(video.fmaps[None]) with
+    # video.fmaps torch.half (depth_video.py:44) => `/ 4.0` and avg_pool2d run in half and the pyramid IS half
+    # (modules/corr.py:97-104); corr_fn widens the gathered per-edge copies with .float() (:120) for the fp32 kernel.
+    # `altcorr_pyramid_f16` takes that half pyramid as it is (f16 matrix cores, fp32 accumulation, fp32 output).
+    # The fp32 entries are the same work from a float32 pyramid (training without autocast).
     Ba = min(B, 64)
-    fml = fm.float() / 4.0
-    pyr = []
-    x = fml
-    for lvl in range(4):
-        pyr.append(x.permute(0, 2, 3, 1).contiguous())
-        x = F.avg_pool2d(x, 2, stride=2)
-    a1 = pyr[0][ii[:Ba]].contiguous()
-    a2 = [pyr[lvl][jj[:Ba]].contiguous() for lvl in range(4)]
+    pixa = Ba * H * W
+    alt_flop_per_pix = 4 * (2 * r + 2) ** 2 * 128 * 2
+    cf = c[:Ba].contiguous()
+    iia_, jja_ = ii[:Ba].contiguous(), jj[:Ba].contiguous()
+
+    def build_pyramid(x):
+        pyr_ = []
+        for lvl in range(4):
+            pyr_.append(x.permute(0, 2, 3, 1).contiguous())
+            x = F.avg_pool2d(x, 2, stride=2)
+        return pyr_
+
+    pyr_h = build_pyramid(fm / 4.0)                 # half, like AltCorrBlock.__init__ on half fmaps
+    assert pyr_h[0].dtype == torch.float16
+    ms_h = timeit(lambda: db.altcorr_pyramid_forward(pyr_h, cf, iia_, jja_, r), 5)
+    alt16_bytes_per_pix = (128 * 2 + sum(128 * 2 / 4 ** l for l in range(4)) + 8 + 4 * (2 * r + 1) ** 2 * 4)
+    out["altcorr_pyramid_f16"] = dict(
+        gpix_per_s=pixa / ms_h / 1e6, ms=ms_h, edges=Ba, tflops=pixa * alt_flop_per_pix / ms_h / 1e9,
+        frac_of_f16_mfma_peak=pixa * alt_flop_per_pix / ms_h / 1e9 / 2500.0,
+        algorithmic_bytes_per_pix=alt16_bytes_per_pix, hbm_gbs=pixa * alt16_bytes_per_pix / ms_h / 1e6,
+        frac_of_8TBs=pixa * alt16_bytes_per_pix / ms_h / 1e6 / HBM_PEAK_GBS,
+        kernel="altcorr_wave_f16<3, 4, float>: half pyramid (the SLAM path's dtype) -> fp32 corr, one launch over (pyramid, ii, jj); "
+               "useful flops only (the box GEMM does ~3x more); bytes = fmap1 row once + fmap2 share + coords + fp32 output")
+    # the reference's call sequence on that pyramid: gather + .float() per level, then the fp32 operator (corr.py:113-120)
+    def run_ref_sequence():
+        return [db.altcorr_forward(pyr_h[0][iia_].float(), pyr_h[lvl][jja_].float(), (cf[:, None] / 2 ** lvl).contiguous(), r)[0]
+                for lvl in range(4)]
+    ms_seq = timeit(run_ref_sequence, 3)
+    out["altcorr_pyramid_f16"]["reference_call_sequence_ms"] = ms_seq
+    out["altcorr_pyramid_f16"]["speedup_vs_reference_call_sequence"] = ms_seq / ms_h
+    pyr = build_pyramid(fm.float() / 4.0)           # float32 pyramid
+    a1 = pyr[0][iia_].contiguous()
+    a2 = [pyr[lvl][jja_].contiguous() for lvl in range(4)]
     ca = [(c[:Ba, None] / 2 ** lvl).contiguous() for lvl in range(4)]
 
     def run_alt():
         return [db.altcorr_forward(a1, a2[lvl], ca[lvl], r)[0] for lvl in range(4)]
 
     ms_alt = timeit(run_alt, 3)
-    pixa = Ba * H * W
     alt_bytes_per_pix = (4 * 128 * 4 + sum(128 * 4 / 4 ** l for l in range(4)) + 4 * 8 + 4 * (2 * r + 1) ** 2 * 4)
-    alt_flop_per_pix = 4 * (2 * r + 2) ** 2 * 128 * 2
     out["altcorr_fp32"] = dict(gpix_per_s=pixa / ms_alt / 1e6, ms=ms_alt, edges=Ba,
                                algorithmic_bytes_per_pix=alt_bytes_per_pix,
                                tflops=pixa * alt_flop_per_pix / ms_alt / 1e9,
                                frac_of_fp32_peak=pixa * alt_flop_per_pix / ms_alt / 1e9 / 157.3,
                                hbm_gbs=pixa * alt_bytes_per_pix / ms_alt / 1e6,
                                frac_of_8TBs=pixa * alt_bytes_per_pix / ms_alt / 1e6 / 8000.0,
-                               kernel="altcorr_forward_mfma<3> (fp32 MFMA; useful flops only, the box GEMM does 2-3x more)")
+                               kernel="altcorr_forward_mfma<3, float, float> (fp32 MFMA, float32 maps; useful flops only, the box GEMM does 2-3x more)")
     # the same work through the fused pyramid entry point (no per-edge feature copies, one launch)
-    cf = c[:Ba].contiguous()
-    ms_pyr = timeit(lambda: db.altcorr_pyramid_forward(pyr, cf, ii[:Ba].contiguous(), jj[:Ba].contiguous(), r), 3)
+    ms_pyr = timeit(lambda: db.altcorr_pyramid_forward(pyr, cf, iia_, jja_, r), 3)
     out["altcorr_pyramid_fp32"] = dict(gpix_per_s=pixa / ms_pyr / 1e6, ms=ms_pyr, edges=Ba,
                                        tflops=pixa * alt_flop_per_pix / ms_pyr / 1e9,
                                        frac_of_fp32_peak=pixa * alt_flop_per_pix / ms_pyr / 1e9 / 157.3,
-                                       kernel="altcorr_pyramid_mfma<3>: AltCorrBlock.corr_fn in one launch over (pyramid, ii, jj)")
+                                       kernel="altcorr_pyramid_mfma<3, float>: AltCorrBlock.corr_fn in one launch over a float32 (pyramid, ii, jj)")
     # reproject + motion features of the update operator (DepthVideo.reproject + factor_graph.py:203-205), fused:
     # per pixel 4 B disparity + 8 B target in, 8 B coords + 4 B valid + 16 B features out
     Ea = len(prob.ii)
@@ -335,13 +422,37 @@ def cpu_model():
     return "unknown"
 
 
+def main_stub(args, rank, world):
+    """--stub-backend: the launch / rendezvous / collective plumbing of a multi-rank run on CPU (gloo)."""
+    import torch.distributed as dist
+    dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    dt, _, info, _ = bench_ba(args, rank, world, dev, args.keyframes, args.edges_total or 32, H=8, W=8, steps=args.steps,
+                              profile=False)
+    if rank == 0:
+        print(json.dumps({"metric": "BA update iters/sec (STUB BACKEND: plumbing only, not a measurement)", "value": None,
+                          "valid": False, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"workload": "stub", "edges_total": info["E"], "edges_local_rank0": info["E_local"],
+                                     "stub_allreduce_sum": info.get("stub_allreduce_sum")}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))      # this process never touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         "(or without a launcher: bench.py starts its own ranks)")
+    if args.stub_backend:
+        return main_stub(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
     # rehearsal of the multi-rank path on a one-GPU box: all ranks on device 0, gloo instead of RCCL, and the
     # cooperative solver launch (two ranks' spinning grids cannot both be resident on one GPU).  Not a measurement.
@@ -396,11 +507,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if corr is not None:  # edges are independent: aggregate rate = sum over ranks
-            t = torch.tensor([corr["volume_fp16"]["gpix_per_s"], corr["altcorr_fp32"]["gpix_per_s"]],
+            t = torch.tensor([corr["volume_fp16"]["gpix_per_s"], corr["altcorr_fp32"]["gpix_per_s"],
+                              corr["altcorr_pyramid_f16"]["gpix_per_s"]],
                              dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t)
             corr["volume_fp16"]["gpix_per_s_all_ranks"] = float(t[0])
             corr["altcorr_fp32"]["gpix_per_s_all_ranks"] = float(t[1])
+            corr["altcorr_pyramid_f16"]["gpix_per_s_all_ranks"] = float(t[2])
 
     if rank == 0:
         K = args.steps

@@ -1269,7 +1269,7 @@ struct AwArgs {
 };
 
 template <int R, int NST, typename TO>
-__global__ __launch_bounds__(64) void altcorr_wave_f16(const AwArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void altcorr_wave_f16(const AwArgs a) {
   constexpr int RD = 2 * R + 1, NT = RD + 1;
   constexpr int MAXBLK = AwCfg<R>::MAXBLK, CP = AwCfg<R>::CP, NRING = AwCfg<R>::NRING;
   static_assert(NRING * 1024 <= AwCfg<R>::LDS_FLOATS, "ring inside the D buffer");

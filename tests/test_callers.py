@@ -147,6 +147,10 @@ def test_backend_shaped_update(backends, oracle):
         fused, = backends.altcorr_pyramid_forward([p.float() for p in corr_op.pyramid], coords1[0, v].contiguous(),
                                                   i1, i2, 3)
         assert torch.equal(fused, corr1[0])
+        # the half pyramid as AltCorrBlock holds it, straight into the f16 matrix-core entry point: no `.float()` copies
+        fused_h, = backends.altcorr_pyramid_forward(corr_op.pyramid, coords1[0, v].contiguous(), i1, i2, 3)
+        assert fused_h.dtype == torch.float32
+        assert float((fused_h - corr1[0]).abs().max()) <= 2e-6 * float(corr1.abs().max())
         for k in (0, int(v.sum()) - 1):                              # first and last edge of the chunk vs the oracle
             for l in (0, 3):
                 f1 = corr_op.pyramid[0][0, i1[k]].float().cpu().numpy()[None]
