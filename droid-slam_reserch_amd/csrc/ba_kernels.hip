@@ -1821,7 +1821,17 @@ __global__ void ba_pose_retr_kernel(BaView v, float* __restrict__ poses, const d
     }
     if (status_mirror) {  // host-visible copy: the wrapper reads it at its next call without synchronising
       __hip_atomic_store(status_mirror + 1, v.hdr[HDR_M], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(status_mirror, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(status_mirror, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // Errors are STICKY: words 2 / 3 count the iterations that ended with a contract violation or a stalled solve
+      // and OR their bits.  Only the device writes them (one kernel at a time per workspace), the host only reads
+      // and remembers the count it has reported, so a violation of call k survives call k+1 being enqueued (and
+      // resetting the workspace status) before the host looks.
+      if (st & (STATUS_BAD_INDEX | STATUS_ETA_ROWS | STATUS_CHOL_STALL)) {
+        const int cnt = __hip_atomic_load(status_mirror + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const int bits = __hip_atomic_load(status_mirror + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(status_mirror + 3, bits | st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(status_mirror + 2, cnt + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
   if (p >= v.P) return;

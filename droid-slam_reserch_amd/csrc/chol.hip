@@ -1323,10 +1323,13 @@ struct PersistState {
 static PersistState g_persist[64];
 static std::mutex g_persist_mu;
 
-static void persist_enter(hipStream_t s) {
+// Returns the lock: the caller keeps it until its spinning grid is ENQUEUED, so that another host thread cannot record
+// its "previous stream" event in front of this launch (with the lock released before the launch, thread B
+// could order itself behind thread A's stream before A's grid was in it, and the two grids could overlap).
+static std::unique_lock<std::mutex> persist_enter(hipStream_t s) {
+  std::unique_lock<std::mutex> lock(g_persist_mu);
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
-  std::lock_guard<std::mutex> lock(g_persist_mu);
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return lock;
   PersistState& st = g_persist[dev];
   if (st.any && st.last != s) {
     if (!st.ev && hipEventCreateWithFlags(&st.ev, hipEventDisableTiming) != hipSuccess) st.ev = nullptr;
@@ -1335,6 +1338,20 @@ static void persist_enter(hipStream_t s) {
   }
   st.last = s;
   st.any = true;
+  return lock;
+}
+
+// The single-launch factorisation leaves the factored diagonal tiles L_jj in the side buffer `ldiag`, not in the
+// matrix (the other panel workgroups still read the unfactored tile).  The per-step back-substitution reads them from
+// the matrix: this copies the lower triangles back when that kernel has to follow a single-launch factorisation
+// (cooperative launch of the back-substitution refused).
+__global__ __launch_bounds__(256) void chol_ldiag_to_sys_kernel(double* __restrict__ S, int n, int ld,
+                                                                const double* __restrict__ Ldiag) {
+  const int j = blockIdx.x, c0 = j * NB, wk = min(NB, n - c0);
+  for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) {
+    const int i = idx / NB, c = idx % NB;
+    if (i < wk && c <= i) S[(size_t)(c0 + i) * ld + c0 + c] = Ldiag[(size_t)j * NB * NB + idx];
+  }
 }
 
 static bool chol_cooperative() {
@@ -1355,7 +1372,7 @@ bool launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* f
     static const int env_cap = getenv("DROID_CHOL_GRID") ? atoi(getenv("DROID_CHOL_GRID")) : 0;  // diagnostics
     if (env_cap >= 8 && env_cap < cap) cap = env_cap;
     const int grid = total < cap ? total : cap;
-    persist_enter(s);
+    auto lock = persist_enter(s);
     if (chol_cooperative()) {
       void* args[] = {&sys, &n, &ld, &fail_flag, &lm, &ep, &flags, &ldiag};
       if (hipLaunchCooperativeKernel((const void*)chol_factor_persistent_kernel, dim3(grid), dim3(512), args, 0, s) == hipSuccess)
@@ -1377,16 +1394,19 @@ void launch_chol_backsolve(double* sys, int n, int ld, double* x, int* flags, do
                            hipStream_t s, bool factor_single) {
   const int nb = (n + NB - 1) / NB;
   if (flags != nullptr && nb >= 2 && nb <= BSP_MAX_BLOCKS) {
-    persist_enter(s);
+    auto lock = persist_enter(s);
     double* ld_arg = factor_single ? ldiag : nullptr;
     const void* fn = factor_single ? (const void*)chol_backsolve_persistent_kernel<true>
                                    : (const void*)chol_backsolve_persistent_kernel<false>;
     if (chol_cooperative()) {
       void* args[] = {&sys, &n, &ld, &x, &err, &ld_arg};
-      if (hipLaunchCooperativeKernel(fn, dim3(nb), dim3(256), args, 0, s) == hipSuccess) return;
+      static const bool force_refusal = getenv("DROID_CHOL_FORCE_BS_REFUSAL") != nullptr;   // test switch
+      if (!force_refusal && hipLaunchCooperativeKernel(fn, dim3(nb), dim3(256), args, 0, s) == hipSuccess) return;
       (void)hipGetLastError();
-      if (factor_single) {  // `x` carries the sentinel preset: the per-step kernels below overwrite all of it
-      }
+      // refused: the per-step kernels below run (`x` carries the sentinel preset, they overwrite all of it).  After a
+      // single-launch factorisation the diagonal tiles must first come back from the side buffer.
+      if (factor_single)
+        hipLaunchKernelGGL(chol_ldiag_to_sys_kernel, dim3(nb), dim3(256), 0, s, sys, n, ld, ldiag);
     } else {
       if (factor_single)
         hipLaunchKernelGGL(chol_backsolve_persistent_kernel<true>, dim3(nb), dim3(256), 0, s, sys, n, ld, x, err, ldiag);

@@ -37,7 +37,10 @@ class _Workspace:
 
     def __init__(self):
         self.buf = None
-        self.mirror = torch.zeros(2, dtype=torch.int32).pin_memory()
+        # {status of the last iteration, depth slots, number of iterations that ended with a violation / a stalled
+        # solve so far, OR of their status bits}: written by the device only (include/droid_backends_hip.h)
+        self.mirror = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.seen = 0      # error count already raised / shown to the caller
 
     def get(self, nbytes, device):
         if self.buf is None or self.buf.numel() < nbytes:
@@ -105,7 +108,7 @@ def ba_status(workspace=None):
     st, m = ctypes.c_int(0), ctypes.c_int(0)
     _lib.check(lib.droid_ba_status(workspace.data_ptr(), _stream(), ctypes.byref(st), ctypes.byref(m)), "ba_status")
     if obj is not None:
-        obj.mirror.zero_()   # the caller has seen this call's status: the next `ba` does not raise it again
+        obj.seen = int(obj.mirror[2])   # droid_ba_status synchronised: the caller has seen everything up to here
     return st.value, m.value
 
 
@@ -157,11 +160,12 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     if nbytes == 0:
         raise RuntimeError("droid_backends.ba: bad sizes / window")
     wso = _workspace_obj(dev)
-    prev = int(wso.mirror[0])   # what the previous call on this stream reported (plain host read, no sync)
-    if prev & ~4:
-        prev_m = int(wso.mirror[1])
-        wso.mirror.zero_()
-        _raise_on_status(prev, prev_m, " (previous call on this stream)")
+    # Deferred error report, no sync: the device counts the iterations that ended with a violation or a stalled solve
+    # in page-locked host memory and ORs their bits (sticky: a later call cannot overwrite them); raise once per count.
+    nerr = int(wso.mirror[2])
+    if nerr != wso.seen:
+        wso.seen = nerr
+        _raise_on_status(int(wso.mirror[3]) & ~4, int(wso.mirror[1]), " (an earlier call on this stream)")
     ws = wso.get(nbytes, dev)
     dx = torch.empty((max(P, 0), 6), dtype=torch.float32, device=dev)
     dz = torch.empty((M, H * W), dtype=torch.float32, device=dev)
@@ -172,7 +176,7 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     _lib.check(rc, "ba")
     if _SYNC_CHECK:
         st = ba_status(ws)
-        wso.mirror.zero_()
+        wso.seen = int(wso.mirror[2])
         _raise_on_status(*st)
     return [dx, dz]
 

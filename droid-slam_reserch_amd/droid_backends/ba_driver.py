@@ -84,17 +84,17 @@ class HipBackend:
         _lib.check(self.lib.droid_ba_prepare(p.ii.data_ptr(), p.jj.data_ptr(), E, nbuf, H, W, M, t0, t1,
                                              int(own[0]), int(own[1]), int(motion_only), self.ws.data_ptr(),
                                              self.ws.numel(), s), "ba_prepare")
-        nel = ctypes.c_size_t(0)
-        ptr = self.lib.droid_ba_system(self.ws.data_ptr(), E, nbuf, H, W, t0, t1, M, ctypes.byref(nel))
+        nel_sys = ctypes.c_size_t(0)
+        ptr = self.lib.droid_ba_system(self.ws.data_ptr(), E, nbuf, H, W, t0, t1, M, ctypes.byref(nel_sys))
         off = ptr - self.ws.data_ptr()
-        self.system = self.ws[off:off + nel.value * 8].view(torch.float64)
+        self.system = self.ws[off:off + nel_sys.value * 8].view(torch.float64)
         nel = ctypes.c_size_t(0)
         ptr = self.lib.droid_ba_packed_system(self.ws.data_ptr(), E, nbuf, H, W, t0, t1, M, ctypes.byref(nel))
         off = ptr - self.ws.data_ptr()
         self.packed = self.ws[off:off + nel.value * 8].view(torch.float64)   # lower triangle + rhs row, contiguous
         self.dx = torch.empty((t1 - t0, 6), dtype=torch.float32, device=p.poses.device)
         self.dz = torch.empty((M, H * W), dtype=torch.float32, device=p.poses.device)
-        self._ridx_key = (t1 - t0, nel.value)
+        self._ridx_key = (t1 - t0, nel_sys.value)   # PITCHED element count: reduce_index derives the row pitch from it
 
     def reduce_index(self):
         """Flat indices of the entries of `system` that the solve reads: the lower triangle of the

@@ -190,10 +190,13 @@ double *droid_ba_system(void *workspace, int E, int nbuf, int H, int W, int t0, 
  * deployments with DROID_CHOL_COOPERATIVE=1 or DROID_CHOL_MULTI_LAUNCH=1). */
 int droid_ba_status(const void *workspace, void *stream, int *status_out, int *depth_slots_out);
 
-/* Non-blocking error reporting: `mirror` points to 2 ints of page-locked host memory that the device can
+/* Non-blocking error reporting: `mirror` points to 4 ZEROED ints of page-locked host memory that the device can
  * address (hipHostMalloc / torch pin_memory).  Every droid_ba_solve_update on this workspace then ends by
- * writing {status word, depth slots} there (system-scope stores by the last kernel of the iteration), so the
- * host can inspect the outcome of the PREVIOUS call whenever it likes without synchronising the stream.
+ * writing {status word, depth slots} to words 0 / 1 (system-scope stores by the last kernel of the iteration), and,
+ * when the iteration ended with bit0, bit1 or bit3 set, by incrementing word 2 and OR-ing the status into word 3.
+ * Words 2 / 3 are STICKY -- only the device writes them, nothing resets them -- so a violation of call k is still
+ * there after call k+1 has been enqueued and has reset the workspace's own status word: the host compares word 2
+ * with the count it has already reported, whenever it likes, without synchronising the stream.
  * mirror = NULL detaches.  The registration is host-side (keyed by the workspace address).
  *
  * Preconditions of the phase API on one workspace: droid_ba_build and droid_ba_solve_update alternate on ONE

@@ -81,7 +81,10 @@ print("WORST", worst)
 
 
 @pytest.mark.parametrize("env", [{"DROID_CHOL_GRID": "64"}, {"DROID_CHOL_COOPERATIVE": "1"},
-                                 {"DROID_CHOL_MULTI_LAUNCH": "1"}, {"DROID_CHOL_COOPERATIVE": "1", "DROID_CHOL_GRID": "96"}])
+                                 {"DROID_CHOL_MULTI_LAUNCH": "1"}, {"DROID_CHOL_COOPERATIVE": "1", "DROID_CHOL_GRID": "96"},
+                                 # cooperative back-substitution refused after a single-launch factorisation: the
+                                 # per-step kernels must see the factored diagonal tiles
+                                 {"DROID_CHOL_COOPERATIVE": "1", "DROID_CHOL_FORCE_BS_REFUSAL": "1"}])
 def test_solver_launch_modes_agree(env):
     """64 resident workgroups for 300 tiles (several tiles per workgroup and step), the cooperative launch and the
     per-step fallback: same answer as numpy to 1e-10."""
@@ -128,9 +131,42 @@ def test_violation_is_raised_by_the_next_call_without_sync(backends):
     backends.ba_status()                       # clean slate
     backends.ba(*args(d["eta"][:-1].contiguous()))
     torch.cuda.synchronize()                   # (only so that the test is deterministic)
-    with pytest.raises(RuntimeError, match="previous call.*eta rows"):
+    with pytest.raises(RuntimeError, match="earlier call.*eta rows"):
         backends.ba(*args(d["eta"]))
     backends.ba(*args(d["eta"]))               # reported once; this call runs
+    torch.cuda.synchronize()
+    assert backends.ba_status()[0] & 11 == 0
+
+
+def test_violation_survives_a_later_clean_call_enqueued_before_the_host_looks(backends):
+    """call k violates the eta contract, call k+1 (clean) is enqueued right behind it and resets the
+    workspace status before the host has looked -- the report must not be lost: the device-side error count and
+    bits in the pinned mirror are sticky, and the next `ba` raises."""
+    torch = _torch()
+    from droid_backends import synth
+    from util import to_dev
+    p = synth.make_config("cfg1")
+    d = to_dev(p, torch)
+    args = lambda eta: (d["poses"], d["disps"], d["intrinsics"], d["disps_sens"], d["targets"], d["weights"], eta,
+                        d["ii"], d["jj"], p.t0, p.t1, 1, p.lm, p.ep, False)
+    backends.ba(*args(d["eta"]))
+    torch.cuda.synchronize()
+    backends.ba_status()
+    # enqueue the violating call and a clean one behind it while the stream is still busy with earlier work
+    filler = torch.randn(4096, 4096, device="cuda")
+    for _ in range(20):
+        filler = filler @ filler * 1e-4
+    backends.ba(*args(d["eta"][:-1].contiguous()))
+    backends.ba(*args(d["eta"]))               # nothing to report yet at enqueue time (or at most the count of call k)
+    torch.cuda.synchronize()
+    raised = False
+    try:
+        backends.ba(*args(d["eta"]))
+    except RuntimeError as e:
+        raised = "eta rows" in str(e)
+    if not raised:                              # the host happened to look between the two calls: then it raised there
+        pytest.skip("the violating call had already finished when the clean one was enqueued")
+    backends.ba(*args(d["eta"]))
     torch.cuda.synchronize()
     assert backends.ba_status()[0] & 11 == 0
 
