@@ -3,7 +3,7 @@
 device (phase API) with and without the Schur part, compares A = sum of Hessian blocks, S = E C^-1 E^T, the rhs parts
 against the fp64 oracle's, and propagates each difference through the damped solve in numpy:
     dx(H, b) = (H + diag(ep + lm diag H))^-1 b
-Not a test; the oracle is used as the checker only.  usage: python tools/noise_probe.py [seed] [iterations]"""
+Not a test; the oracle is used as the checker only.  usage: python tools/noise_probe.py [seed] [config]"""
 import ctypes
 import os
 import sys
@@ -19,7 +19,8 @@ from droid_backends import synth
 from util import ba_args, to_dev
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-p = synth.make_config("cfg3", seed=seed)
+cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg3"      # e.g. `noise_probe.py 3 cfg4`: the dense-slot path
+p = synth.make_config(cfg, seed=seed)
 lib = db._lib.load()
 nbuf, H, W = p.disps.shape
 E, M, P = len(p.ii), p.eta.shape[0], p.t1 - p.t0
