@@ -683,6 +683,42 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
     const gbl_f64* slot1 = Ldiag + chol_lfin_offset(n) + (size_t)chol_tile_index(nrb, kp, k) * NB * NB;  // L[kp,k]
     const gbl_f64* slot0 = Ldiag + chol_lfin_offset(n) + (size_t)chol_tile_index(nrb, bi, k) * NB * NB;  // L[bi,k]
     for (int sp = 0; sp < 4; sp++) {
+#ifdef CHOL_DIRECT00
+      // Candidate (i) of DESIGN section 8 (A/B build): the pivot wave takes ITS 16x16 block of the last
+      // strip -- rows 0..15 of L[kp,k], the only operand of D00's last rank-16 update -- straight from the hand-over
+      // slot into MFMA operands (8-byte sc1 loads, data-tagged like the strip loads) and applies the update in front
+      // of the barrier instead of behind it (no LDS stage on the chain for this block).
+      if (sp == 3 && wave == 0) {
+        const gbl_f64* q = slot1 + (size_t)fr * NB + 48 + fg;
+        const bool rowok = c0 + fr < n;
+        double dv[4];
+        int spins = 0;
+        while (true) {
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++)
+            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(dv[kk]) : "v"(q + 4 * kk) : "memory");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          bool there = true;
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) {
+            asm volatile("" : "+v"(dv[kk]));
+            if (rowok && __double_as_longlong(dv[kk]) == CFP_TAG) there = false;
+          }
+          if (__all(there)) break;
+          if (++spins > CFP_SPIN_LIMIT || ((spins & 255) == 0 && cfp_load(abortf) == 1)) {
+            cfp_store(abortf, 1);
+            atomicMax(fail, 2);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const double x = rowok ? dv[kk] : 0.0;
+          tacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x, x, tacc[0], 0, 0, 0);
+        }
+      }
+#endif
       if (grp == 0) load_strip64(B1, slot1, c0, sp, c0, n, fail, abortf);
       else load_strip64(B0, slot0, r0, sp, r0, nrows, fail, abortf);
       __syncthreads();
@@ -701,6 +737,9 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
           if (code[i] & 0x10) {
             if (solve_rows) block_update16(tacc[i], &B0[(16 * rg) * LDP + 16 * sp], &B1[(16 * nt) * LDP + 16 * sp]);
           } else {
+#ifdef CHOL_DIRECT00
+            if (!(sp == 3 && wave == 0))   // done in front of the barrier, from registers
+#endif
             block_update16(tacc[i], &B1[(16 * rg) * LDP + 16 * sp], &B1[(16 * nt) * LDP + 16 * sp]);
           }
         }

@@ -94,6 +94,73 @@ __global__ void tilepass(double* buf, int* flags, unsigned long long* out, int a
   if (acc == 12345.678) out[1] = (unsigned long long)sink[(t + 1) & 255];
 }
 
+// Strip hand-off exactly as the single-launch Cholesky does it (chol.hip: chol_strip_out -> load_strip64): ONE wave of the
+// producer writes a 16-column strip of a 64x64 tile (8 KB, 16-byte stores) into a data-tagged slot (preset to 0xFF
+// bytes, fresh memory every round: no flag, no acknowledgement); 256 threads of the consumer re-read their two 16-byte
+// units until no value carries the tag, meet at a barrier, and the consumer answers with a strip of its own.
+// MODE 0: sc1 stores + sc1 loads (what ships; works across XCDs).  MODE 1: plain stores + L1 invalidate + plain loads
+// (through the producer XCD's own L2: same XCD only) -- candidate (ii) of DESIGN section 8.
+template <int MODE>
+__global__ __launch_bounds__(256) void strippass(double* slots, unsigned long long* out, int a, int b, int rounds) {
+  const int wg = blockIdx.x, t = threadIdx.x;
+  if (wg != a && wg != b) return;
+  double acc = 0;
+  const unsigned long long t0 = wall_clock64();
+  for (int r = 0; r < rounds; r++) {
+    if (*(volatile int*)&g_abort) break;
+    for (int half = 0; half < 2; half++) {
+      const bool producer = (half == 0) == (wg == a);
+      double* slot = slots + ((size_t)2 * r + half) * 4096;       // 64 x 64 doubles, strip = columns 48..63
+      if (producer) {
+        if (t < 64) {
+          const int i0 = t >> 3, j = 48 + (t & 7) * 2;
+#pragma unroll
+          for (int it = 0; it < 8; it++) {
+            f64x2 v = {(double)r + acc * 1e-30, (double)(r + it)};
+            double* q = &slot[(i0 + 8 * it) * 64 + j];
+            if (MODE == 1) *(f64x2*)q = v;
+            else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(v) : "memory");
+          }
+        }
+      } else {
+        const double* p0 = &slot[(t >> 3) * 64 + 48 + (t & 7) * 2];
+        const double* p1 = p0 + 32 * 64;
+        f64x2 v0, v1;
+        int spins = 0;
+        while (true) {
+          if (MODE == 1) {
+            asm volatile("buffer_inv sc0" ::: "memory");
+            v0 = *(volatile f64x2*)p0; v1 = *(volatile f64x2*)p1;
+          } else {
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v0) : "v"(p0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v1) : "v"(p1) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(v0), "+v"(v1));
+          }
+          const bool there = __double_as_longlong(v0[0]) != -1LL && __double_as_longlong(v0[1]) != -1LL &&
+                             __double_as_longlong(v1[0]) != -1LL && __double_as_longlong(v1[1]) != -1LL;
+          if (there) break;
+          if (++spins > 200000) { g_abort = 1; }
+          if (*(volatile int*)&g_abort) break;
+        }
+        acc += v0[0] + v1[1];
+        __syncthreads();
+      }
+    }
+  }
+  if (wg == a && t == 0) out[0] = wall_clock64() - t0;
+  if (acc == 12345.678) out[1] = 1;
+}
+
+template <int MODE>
+void run_strip(const char* what, double* slots, size_t slot_bytes, unsigned long long* out, int a, int b, int rounds, int rate) {
+  hipMemset(slots, 0xFF, slot_bytes);
+  hipDeviceSynchronize();
+  hipLaunchKernelGGL((strippass<MODE>), dim3(256), dim3(256), 0, 0, slots, out, a, b, rounds);
+  unsigned long long h = 0; hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost);
+  printf("8 KB strip, data-tagged slot, WG %d -> WG %d, %s: %.0f ns per hand-off\n", a, b, what, (double)h / rate * 1e6 / rounds / 2);
+}
+
 template <int STORE, int LOAD, int THREADS>
 void run_tile(const char* what, double* buf, int* flags, unsigned long long* out, int a, int b, int rounds, int rate) {
   hipMemset(flags, 0, 1024);
@@ -137,6 +204,15 @@ int main() {
   run_tile<1, 1, 256>("plain 16-byte stores, L1-invalidate + plain loads (same XCD only)", buf, flags, out, 0, same, rounds, rate);
   run_tile<1, 1, 512>("plain 16-byte stores, L1-invalidate + plain loads (same XCD only)", buf, flags, out, 0, same, rounds, rate);
   run_tile<2, 1, 512>("16-byte sc1 stores, L1-invalidate + plain loads (same XCD only)", buf, flags, out, 0, same, rounds, rate);
+  {
+    const int srounds = 1000;
+    const size_t sbytes = (size_t)srounds * 2 * 4096 * 8;
+    double* slots; hipMalloc(&slots, sbytes);
+    run_strip<0>("16-byte sc1 stores, 16-byte sc1 polling loads, same XCD", slots, sbytes, out, 0, same, srounds, rate);
+    run_strip<0>("16-byte sc1 stores, 16-byte sc1 polling loads, other XCD", slots, sbytes, out, 0, diff, srounds, rate);
+    run_strip<1>("plain stores, L1 invalidate + plain polling loads, same XCD (through its L2)", slots, sbytes, out, 0, same, srounds, rate);
+    hipFree(slots);
+  }
   int ab = 0; hipMemcpyFromSymbol(&ab, HIP_SYMBOL(g_abort), 4);
   printf("abort flag: %d (1 = some poll never saw its flag; numbers above are then meaningless)\n", ab);
   return 0;
