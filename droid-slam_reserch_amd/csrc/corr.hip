@@ -285,6 +285,159 @@ static bool launch_corr_small(const T* v, const float* coords, T* c, int B, int 
   return true;
 }
 
+// Mid-size planes (pyramid levels 1-2 at 48x64: rows of 64 / 32 bytes, so a 128-byte line holds 2-4 window rows).  With one
+// thread per query, every lane asks for its 8 window rows in 8 separate instructions, each touching 64 different lines: the
+// same line is requested 2-4 times per query and, with 12 waves streaming 20+ KB each through a 32 KB L1, comes from L2
+// again (PMC r02: 424 B fetched per level-2 query for ~320 touched).  Here the wave loads COOPERATIVELY: in pass `it` lane
+// (q = lane >> 3, j = lane & 7) fetches row j of the window of query 8 it + q, so the 8 rows of a query sit in adjacent
+// lanes of ONE instruction and the memory pipeline merges them into the 2-5 lines they occupy: every line is requested once
+// per query.  The rows travel through a wave-private LDS image [query][row][dwords] (pitch odd: conflict-free both ways) to
+// the lane that owns the query; arithmetic, rounding points and output layout are those of corr_index_forward_kernel.
+template <typename T, int NT> struct RowWords;   // dwords a row load brings (RowLoad) and the taps' place in them
+template <int NT> struct RowWords<__half, NT> { static constexpr int NW = RowLoad<__half, NT>::NW; };
+template <int NT> struct RowWords<float, NT> { static constexpr int NW = NT; };
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void corr_index_forward_coop(const T* __restrict__ volume,
+                                                               const float* __restrict__ coords,
+                                                               T* __restrict__ corr, int H1W1, int H2, int W2,
+                                                               size_t vol_elems, size_t out_bstride, float cscale) {
+  typedef typename Elem<T>::work work;
+  constexpr int RD = 2 * R + 1, NT = RD + 1;
+  static_assert(NT == 8, "eight window rows <-> eight lanes per query");
+  constexpr int NW = RowWords<T, NT>::NW;
+  constexpr bool HALF = sizeof(T) == 2;
+  // image row: half -- the 8 taps themselves (the loader shifts an odd-aligned row into place): 4 dwords, 16-byte LDS
+  // accesses, query pitch 36 dwords (9.2 KB per wave: 16 waves per CU); float -- the 8 dwords as loaded, pitch 65
+  constexpr int RW = HALF ? 4 : NW, PQ = HALF ? NT * RW + 4 : NT * RW + 1;
+  __shared__ __attribute__((aligned(16))) uint32_t sm[4][64 * PQ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* img = sm[wave];
+  const int pix0 = blockIdx.x * 256 + wave * 64;   // first query of this wave
+  const int pix = pix0 + lane;
+  const int b = blockIdx.y;
+  const bool valid = pix < H1W1;
+  const int cpix = valid ? pix : H1W1 - 1;
+  const float x0 = coords[((size_t)b * 2 + 0) * H1W1 + cpix] * cscale;
+  const float y0 = coords[((size_t)b * 2 + 1) * H1W1 + cpix] * cscale;
+  const Bilin bl = bilin_setup(x0, y0, R);
+  const uintptr_t vbeg = reinterpret_cast<uintptr_t>(volume);
+  const uintptr_t vend = vbeg + vol_elems * sizeof(T);
+  const size_t plane_elems = (size_t)H2 * W2;
+  const bool xany = valid && (bl.x1 + NT > 0) && (bl.x1 < W2);
+  // ---- cooperative loads: pass `it` serves queries 8 it .. 8 it + 7
+  const int lq = lane >> 3, lj = lane & 7;
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int q = 8 * it + lq;
+    const int qx1 = __shfl(bl.x1, q), qy1 = __shfl(bl.y1, q);
+    const bool qany = __shfl((int)xany, q) != 0;
+    const int y1 = qy1 + lj;
+    if (qany && y1 >= 0 && y1 < H2) {
+      const T* rp = volume + ((size_t)b * H1W1 + (pix0 + q)) * plane_elems + (ptrdiff_t)y1 * W2 + qx1;
+      const uintptr_t a0 = reinterpret_cast<uintptr_t>(rp) & ~uintptr_t(3);
+      if (a0 >= vbeg && a0 + NW * 4 <= vend) {   // (rows at the two ends of the tensor: the owner loads them itself)
+        const u32a4* src = reinterpret_cast<const u32a4*>(a0);
+        uint32_t w[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) w[k] = src[k];
+        uint32_t* d = img + q * PQ + lj * RW;
+        if constexpr (HALF) {
+          const bool odd = (reinterpret_cast<uintptr_t>(rp) & 2) != 0;
+          uint4 v;
+          v.x = odd ? __builtin_amdgcn_alignbit(w[1], w[0], 16) : w[0];
+          v.y = odd ? __builtin_amdgcn_alignbit(w[2], w[1], 16) : w[1];
+          v.z = odd ? __builtin_amdgcn_alignbit(w[3], w[2], 16) : w[2];
+          v.w = odd ? __builtin_amdgcn_alignbit(w[4], w[3], 16) : w[3];
+          *reinterpret_cast<uint4*>(d) = v;
+        } else {
+#pragma unroll
+          for (int k = 0; k < NW; k++) d[k] = w[k];
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (!valid) return;
+  // ---- the owner of the query collects its window
+  const T* plane = volume + ((size_t)b * H1W1 + pix) * plane_elems;
+  work tap[NT][NT];  // [row j (y)][col i (x)]
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    const int y1 = bl.y1 + j;
+    const bool rowok = xany && (y1 >= 0) && (y1 < H2);
+#pragma unroll
+    for (int i = 0; i < NT; i++) tap[j][i] = (work)0;
+    if (rowok) {
+      const T* rp = plane + (ptrdiff_t)y1 * W2 + bl.x1;
+      const uintptr_t a = reinterpret_cast<uintptr_t>(rp);
+      const uintptr_t a0 = a & ~uintptr_t(3);
+      if (a0 >= vbeg && a0 + NW * 4 <= vend) {
+        const uint32_t* d = img + lane * PQ + j * RW;
+        if constexpr (HALF) {
+          const uint4 v4 = *reinterpret_cast<const uint4*>(d);
+          const uint32_t w[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+          for (int k = 0; k < NT / 2; k++) {
+            tap[j][2 * k] = __half2float(__ushort_as_half((unsigned short)(w[k] & 0xffffu)));
+            tap[j][2 * k + 1] = __half2float(__ushort_as_half((unsigned short)(w[k] >> 16)));
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NT; k++) tap[j][k] = __uint_as_float(d[k]);
+        }
+      } else {  // first / last elements of the whole tensor only
+#pragma unroll 1
+        for (int i = 0; i < NT; i++) {
+          const int x1 = bl.x1 + i;
+          const work v = (x1 >= 0 && x1 < W2) ? Elem<T>::load(rp + i) : (work)0;
+#pragma unroll
+          for (int i2 = 0; i2 < NT; i2++)
+            if (i2 == i) tap[j][i2] = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NT; i++) {
+        const int x1 = bl.x1 + i;
+        if (x1 < 0 || x1 >= W2) tap[j][i] = (work)0;
+      }
+    }
+  }
+  const float one = 1.0f;
+  const work w00 = Elem<T>::round((work)f32_value((one - bl.dx) * (one - bl.dy)));  // tap (a  ,c  )   ck:55-65
+  const work w01 = Elem<T>::round((work)f32_value((one - bl.dx) * bl.dy));          // tap (a  ,c+1)
+  const work w10 = Elem<T>::round((work)f32_value(bl.dx * (one - bl.dy)));          // tap (a+1,c  )
+  const work w11 = Elem<T>::round((work)f32_value(bl.dx * bl.dy));                  // tap (a+1,c+1)
+  T* out = corr + (size_t)b * out_bstride + pix;
+#pragma unroll
+  for (int a = 0; a < RD; a++) {
+#pragma unroll
+    for (int c = 0; c < RD; c++) {
+      work acc = Elem<T>::mul(tap[c][a], w00);  // 0 + p == p exactly
+      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a], w01));
+      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c][a + 1], w10));
+      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a + 1], w11));
+      Elem<T>::store(out + (size_t)(a * RD + c) * H1W1, acc);
+    }
+  }
+}
+
+// rows of at most 64 bytes (two or more window rows per 128-byte line), radius 3, half / float
+template <typename T, int R>
+static bool launch_corr_coop(const T* v, const float* coords, T* c, int B, int HW, int H2, int W2, size_t vol_elems,
+                             size_t obs, float cs, hipStream_t s) {
+  if constexpr (R != 3 || sizeof(T) > 4) {
+    return false;
+  } else {
+    static const bool off = (getenv("DROID_CORR_NO_COOP") != nullptr);  // diagnostics: the per-lane row-load kernel
+    if (off || W2 * (int)sizeof(T) > 64 || (HW & 63) != 0) return false;
+    hipLaunchKernelGGL((corr_index_forward_coop<T, R>), dim3((HW + 255) / 256, B), dim3(256), 0, s, v, coords, c, HW, H2, W2,
+                       vol_elems, obs, cs);
+    return true;
+  }
+}
+
 // Any radius (slow path): taps are re-read per output.
 template <typename T>
 __global__ __launch_bounds__(256) void corr_index_forward_generic(const T* __restrict__ volume,
@@ -330,6 +483,7 @@ static int corr_index_forward_t(const void* volume, const float* coords, void* c
   const size_t obs = (size_t)(2 * r + 1) * (2 * r + 1) * HW;
   if (r == 3 && launch_corr_small<T, 3>(v, coords, c, B, HW, H2, W2, obs, 1.0f, s)) return 0;
   if (r == 4 && launch_corr_small<T, 4>(v, coords, c, B, HW, H2, W2, obs, 1.0f, s)) return 0;
+  if (r == 3 && launch_corr_coop<T, 3>(v, coords, c, B, HW, H2, W2, vol_elems, obs, 1.0f, s)) return 0;
   if (r == 3)
     hipLaunchKernelGGL((corr_index_forward_kernel<T, 3>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems, obs, 1.0f);
   else if (r == 4)
@@ -368,6 +522,7 @@ static int corr_pyramid_forward_t(const void* const* volumes, const float* coord
     const float cs = 1.0f / (float)(1 << l);
     if (r == 3 && launch_corr_small<T, 3>(v, coords, c, B, HW, H2, W2, obs, cs, s)) continue;
     if (r == 4 && launch_corr_small<T, 4>(v, coords, c, B, HW, H2, W2, obs, cs, s)) continue;
+    if (r == 3 && launch_corr_coop<T, 3>(v, coords, c, B, HW, H2, W2, vol_elems, obs, cs, s)) continue;
     if (r == 3)
       hipLaunchKernelGGL((corr_index_forward_kernel<T, 3>), grid, block, 0, s, v, coords, c, HW, H2, W2, vol_elems, obs, cs);
     else

@@ -1,5 +1,6 @@
 import sys, os, json
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/droid-slam_reserch_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "droid-slam_reserch_amd"))
 import numpy as np, torch, torch.nn.functional as F
 import droid_backends as db
 from droid_backends import synth
