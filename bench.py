@@ -387,6 +387,27 @@ def cpu_baseline(budget_s=15.0):
                                     sample=f"1 iteration of the 64-keyframe/512-edge 48x64 graph (configs[1]), {d1:.1f} s")
     except Exception as e:  # pragma: no cover
         log("single-thread baseline skipped:", e)
+    # second opinion: configs[0] (8 keyframes / 32 edges, 48x64) as a dense batched PyTorch-CPU
+    # computation shaped like the reference's geom/ba.py, all host threads; checked against the C restatement
+    try:
+        from oracle import torch_dense_ba
+        torch.set_num_threads(cores)
+        p1 = synth.make_config("cfg1")
+        a1 = (p1.poses, p1.disps, p1.intrinsics, p1.disps_sens, p1.targets, p1.weights, p1.eta, p1.ii, p1.jj, p1.t0, p1.t1)
+        torch_dense_ba.ba_step(*a1, p1.lm, p1.ep)
+        t0 = time.perf_counter()
+        dx1, dz1, _ = torch_dense_ba.ba_step(*a1, p1.lm, p1.ep)
+        dts = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        o1 = oracle.ba(*a1, 1, p1.lm, p1.ep, False)
+        dto = time.perf_counter() - t0
+        out["second_opinion_cfg1"] = dict(
+            torch_dense_iters_per_s=1.0 / dts, oracle_iters_per_s=1.0 / dto, cores=cores,
+            max_abs_dx_difference=float(np.abs(dx1 - o1["dx"]).max()), max_abs_dz_difference=float(np.abs(dz1 - o1["dz"]).max()),
+            sample="1 iteration of the 8-keyframe / 32-edge 48x64 graph (BASELINE configs[0]): oracle/torch_dense_ba.py "
+                   f"(float64, {cores} threads) {dts * 1e3:.0f} ms vs the C restatement {dto * 1e3:.0f} ms")
+    except Exception as e:  # pragma: no cover
+        log("second-opinion baseline skipped:", e)
     # correlation lookups on the CPU: the numpy restatement (one thread), 2 edges, 4 levels each
     try:
         rng = np.random.default_rng(0)

@@ -8,7 +8,11 @@
 namespace droid {
 
 constexpr int LIN_THREADS = 256;
+#ifdef LIN_PPT_AB
+constexpr int LIN_PPT = LIN_PPT_AB;              // A/B builds (tools/ab_test.sh)
+#else
 constexpr int LIN_PPT = 2;                       // pixels per thread per chunk
+#endif
 constexpr int LIN_CP = LIN_THREADS * LIN_PPT;    // pixels per workgroup chunk
 constexpr int CHOL_NB = 64;                      // Cholesky block size
 // row pitch of the augmented system in doubles: 128-byte rows, so 64-column tiles never share a cache line

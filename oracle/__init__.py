@@ -14,6 +14,8 @@ outputs of the reference itself.
 * ``ba_oracle.c`` / ``ba_oracle_impl.h``: plain-C restatement of ``src/droid_kernels.cu``
   (``ba``, ``frame_distance``, ``projmap``, ``iproj``), fp64 ("truth") and fp32 variants.
 * ``corr.py``: numpy restatement of ``src/correlation_kernels.cu`` / ``src/altcorr_kernel.cu``.
+* ``torch_dense_ba.py``: one BA iteration as a dense batched PyTorch-CPU computation shaped like ``geom/ba.py`` with the
+  CUDA path's constants -- the second-opinion CPU baseline of BASELINE.md section 4 and an independent pin of the C code.
 """
 from __future__ import annotations
 

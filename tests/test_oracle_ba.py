@@ -346,3 +346,22 @@ def test_storage_f32_equals_chained_single_iterations(oracle, synth):
     plain = oracle.ba(*ba_args(p), 1, p.lm, p.ep, False)
     assert np.abs(plain["disps"] - one["disps"]).max() < 4e-7 * max(1.0, np.abs(plain["disps"]).max())
     assert np.abs(plain["poses"] - one["poses"]).max() < 2e-7
+
+
+@pytest.mark.parametrize("variant", ["cfg1", "stereo", "rgbd"])
+def test_torch_dense_formulation_agrees(oracle, synth, variant):
+    """The second-opinion CPU baseline of BASELINE.md section 4 (oracle/torch_dense_ba.py: batched PyTorch, 4x4 pose
+    matrices, Jacobians from dX'/dxi = [w I | -[X']x], J_i = -J_j Adj(T_ij), dense Schur + Cholesky) shares no code
+    with the C restatement: one iteration must agree to float32-input rounding."""
+    from oracle import torch_dense_ba
+    if variant == "cfg1":
+        p = synth.make_config("cfg1")
+    elif variant == "stereo":
+        p = synth.make_ba_problem(N=5, E=12, H=8, W=10, seed=6, stereo=True)
+    else:
+        p = synth.make_ba_problem(N=5, E=12, H=8, W=10, seed=5, rgbd=True)
+    dx, dz, kx = torch_dense_ba.ba_step(*ba_args(p), p.lm, p.ep)
+    o = oracle.ba(*ba_args(p), 1, p.lm, p.ep, False)
+    assert np.array_equal(kx, o["kx"])
+    assert np.abs(dx - o["dx"]).max() < 1e-6 * max(1e-3, np.abs(o["dx"]).max())
+    assert np.abs(dz - o["dz"]).max() < 1e-6 * max(1e-3, np.abs(o["dz"]).max())
