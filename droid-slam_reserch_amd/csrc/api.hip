@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 
@@ -213,6 +214,8 @@ int droid_ba_prepare(const int64_t* ii, const int64_t* jj, int E, int nbuf, int 
   v.own1 = own1 > nbuf ? nbuf : own1;
   v.motion_only = motion_only ? 1 : 0;
   launch_prep(v, ii, jj, (hipStream_t)stream);
+  // overlap mode: no reduced rows of any iteration of this call are in `sys` yet (epochs start at 1)
+  (void)hipMemsetAsync(v.ov_ready, 0, sizeof(int) * ((size_t)(v.n + 1 + CHOL_NB - 1) / CHOL_NB), (hipStream_t)stream);
   return check_hip("ba_prepare");
 }
 
@@ -269,6 +272,66 @@ int droid_ba_unpack_system(int E, int nbuf, int H, int W, int M, int t0, int t1,
   if (rc) return rc;
   launch_unpack_system(v, (hipStream_t)stream);
   return check_hip("ba_unpack_system");
+}
+
+// ---- overlap of the all-reduce with the solve (multi-GPU) ------------------------------------------------------
+// Row chunks of the packed system by block rows of 64: 2, 3, 4, 5, 5, ... block rows -- the first chunk small
+// (the factorisation starts on it), the later ones larger (they arrive long before the diagonal chain reaches them).
+static int overlap_bounds(int n, int max_chunks, int* brow /*[max_chunks + 1]*/) {
+  const int nrb = (n + 1 + CHOL_NB - 1) / CHOL_NB;
+  int nc = 0, b = 0, size = 2;
+  brow[0] = 0;
+  while (b < nrb && nc < max_chunks) {
+    b = (nc + 1 == max_chunks || b + size >= nrb) ? nrb : b + size;
+    brow[++nc] = b;
+    if (size < 5) size++;
+  }
+  return nc;
+}
+
+int droid_ba_overlap_plan(int t0, int t1, int max_chunks, int* nchunks_out, size_t* packed_offsets) {
+  if (t1 <= t0 || max_chunks < 1 || max_chunks > 32 || !nchunks_out || !packed_offsets)
+    return fail(DROID_E_ARG, "ba_overlap_plan: bad %s", "argument");
+  const int n = 6 * (t1 - t0);
+  int brow[33];
+  const int nc = overlap_bounds(n, max_chunks, brow);
+  for (int c = 0; c <= nc; c++) packed_offsets[c] = packed_offset(std::min(CHOL_NB * brow[c], n + 1));
+  *nchunks_out = nc;
+  return DROID_OK;
+}
+
+int droid_ba_unpack_chunk(int E, int nbuf, int H, int W, int M, int t0, int t1, int chunk, int max_chunks, float lm,
+                          float ep, int epoch, void* workspace, size_t workspace_bytes, void* stream) {
+  BaView v;
+  int rc = ba_view(v, workspace, workspace_bytes, E, nbuf, H, W, t0, t1, M, 0);
+  if (rc) return rc;
+  int brow[33];
+  if (max_chunks < 1 || max_chunks > 32) return fail(DROID_E_ARG, "ba_unpack_chunk: bad %s", "max_chunks");
+  const int nc = overlap_bounds(v.n, max_chunks, brow);
+  if (chunk < 0 || chunk >= nc || epoch <= 0) return fail(DROID_E_ARG, "ba_unpack_chunk: bad %s", "chunk / epoch");
+  const int row0 = std::min(CHOL_NB * brow[chunk], v.n + 1), row1 = std::min(CHOL_NB * brow[chunk + 1], v.n + 1);
+  launch_unpack_rows(v, row0, row1, (double)lm, (double)ep, brow[chunk], brow[chunk + 1], epoch, (hipStream_t)stream);
+  return check_hip("ba_unpack_chunk");
+}
+
+int droid_ba_solve_update_overlap(float* poses, float* disps, const float* intrinsics, const float* weights,
+                                  const int64_t* ii, const int64_t* jj, int E, int nbuf, int H, int W, int M,
+                                  int t0, int t1, int epoch, int motion_only, float* dx_out, float* dz_out,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  BaView v;
+  int rc = ba_view(v, workspace, workspace_bytes, E, nbuf, H, W, t0, t1, M, motion_only);
+  if (rc) return rc;
+  if (!poses || !disps) return fail(DROID_E_ARG, "ba: null %s", "state pointer");
+  if (!motion_only && (!intrinsics || (E > 0 && (!weights || !ii || !jj))))
+    return fail(DROID_E_ARG, "ba: null %s", "intrinsics/weights/edges");
+  if (E <= 0 || epoch <= 0) return fail(DROID_E_ARG, "ba_solve_update_overlap: needs %s", "edges (the build presets the solver scratch) and epoch > 0");
+  hipStream_t s = (hipStream_t)stream;
+  if (!launch_chol_factor_overlap(v.sys, v.n, v.ld, v.hdr + HDR_CHOL_FAIL, v.bs_flags, v.ldiag, v.ov_ready, epoch, s))
+    return fail(DROID_E_ARG, "ba_solve_update_overlap: %s", "the single-launch solver is not available for this system (unpack and call droid_ba_solve_update)");
+  launch_chol_backsolve(v.sys, v.n, v.ld, v.xsol, v.bs_flags, v.ldiag, v.hdr + HDR_CHOL_FAIL, s, true);
+  launch_update(v, poses, disps, intrinsics, weights, ii, jj, v.xsol, dx_out, dz_out, motion_only != 0, s,
+                mirror_of(workspace));
+  return check_hip("ba_solve_update_overlap");
 }
 
 int droid_ba_solve_update(float* poses, float* disps, const float* intrinsics, const float* weights,

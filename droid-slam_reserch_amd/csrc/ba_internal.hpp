@@ -87,6 +87,7 @@ struct BaView {
   float* dx;               // [P][6]
   int* bs_flags;           // [chol_flag_words(n)] hand-off flags of the single-launch factorisation
   double* ldiag;           // [ceil(n/64)][64][64] factored diagonal tiles, then the hand-over slots of the panel tiles
+  int* ov_ready;           // [block rows of the system] overlap mode: epoch of the last iteration whose reduced rows are in `sys`
 };
 
 struct BaSizes {
@@ -157,6 +158,7 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.bs_flags = static_cast<int*>(take(sizeof(int) * chol_flag_words(v.n)));   // directly after xsol: one fill presets both
   v.ldiag = static_cast<double*>(take(sizeof(double) * chol_ldiag_doubles(v.n)));
   v.dx = static_cast<float*>(take(sizeof(float) * ((size_t)v.n + 8)));
+  v.ov_ready = static_cast<int*>(take(sizeof(int) * ((size_t)(v.n + 1 + CHOL_NB - 1) / CHOL_NB + 8)));
   return off;
 }
 
@@ -193,6 +195,11 @@ void launch_update(const BaView& v, float* poses, float* disps, const float* int
 void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
                        int* flags, double* ldiag, hipStream_t s, bool preset_done = false);
 
+// Overlap mode (multi-GPU): rows [row0, row1) of the all-reduced packed system -> pitched matrix, damped; then
+// ready[block rows b0..b1) = epoch for the factorisation that is already running (launch_chol_factor_overlap).
+void launch_unpack_rows(const BaView& v, int row0, int row1, double lm, double ep, int b0, int b1, int epoch, hipStream_t s);
+bool launch_chol_factor_overlap(double* sys, int n, int ld, int* fail_flag, int* flags, double* ldiag,
+                                const int* ready, int epoch, hipStream_t s);
 // launch_chol_factor returns whether the single-launch kernel ran; pass that to launch_chol_backsolve
 bool launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag, int* flags,
                         double* ldiag, hipStream_t s);

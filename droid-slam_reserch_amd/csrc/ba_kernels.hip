@@ -1859,11 +1859,39 @@ __global__ __launch_bounds__(256) void ba_unpack_kernel(BaView v) {
   }
 }
 
+// overlap mode: a chunk of rows, with the damping diag += ep + lm diag (dk:1197) the factorisation would apply --
+// it is already running and must not touch rows that are not there yet
+__global__ __launch_bounds__(256) void ba_unpack_rows_kernel(BaView v, int row0, int row1, double lm, double ep) {
+  for (int row = row0 + blockIdx.x; row < row1; row += gridDim.x) {
+    const double2* src = reinterpret_cast<const double2*>(v.psys + packed_offset(row));
+    double2* dst = reinterpret_cast<double2*>(v.sys + (size_t)row * v.ld);
+    const int n2 = (row == v.n) ? (v.n + 1) / 2 : (row + 2) / 2;
+    for (int c = threadIdx.x; c < n2; c += 256) {
+      double2 x = src[c];
+      if (row < v.n && (row >> 1) == c) {
+        if (row & 1) x.y += ep + lm * x.y;
+        else x.x += ep + lm * x.x;
+      }
+      dst[c] = x;
+    }
+  }
+}
+// runs behind ba_unpack_rows_kernel in stream order: its rows are in memory (end-of-kernel release)
+__global__ void ba_set_ready_kernel(int* __restrict__ ready, int b0, int b1, int epoch) {
+  const int b = b0 + (int)threadIdx.x;
+  if (b < b1) __hip_atomic_store(ready + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
 void launch_unpack_system(const BaView& v, hipStream_t s) {
   if (v.n > 0) hipLaunchKernelGGL(ba_unpack_kernel, dim3(min(v.n + 1, 1024)), dim3(256), 0, s, v);
+}
+
+void launch_unpack_rows(const BaView& v, int row0, int row1, double lm, double ep, int b0, int b1, int epoch, hipStream_t s) {
+  if (row1 > row0) hipLaunchKernelGGL(ba_unpack_rows_kernel, dim3(min(row1 - row0, 256)), dim3(256), 0, s, v, row0, row1, lm, ep);
+  if (b1 > b0) hipLaunchKernelGGL(ba_set_ready_kernel, dim3(1), dim3(64), 0, s, v.ov_ready, b0, b1, epoch);
 }
 
 void launch_prep(const BaView& v, const int64_t* ii, const int64_t* jj, hipStream_t s) {

@@ -362,7 +362,7 @@ __device__ __forceinline__ void strip_update(f64x4 (&acc)[4], const lds_f64* Lr,
 template <int NN>
 __device__ __forceinline__ void frag_load_global(f64x4 (&acc)[4], const gbl_f64* __restrict__ S, int ld,
                                                  int r0, int q0, int rg, int nt0, int row_end, int col_end,
-                                                 bool lower) {
+                                                 bool lower, bool coh = false) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -372,7 +372,8 @@ __device__ __forceinline__ void frag_load_global(f64x4 (&acc)[4], const gbl_f64*
       const int li = 16 * rg + g + 4 * i, lj = 16 * (nt0 + nn) + r;
       const int row = r0 + li, col = q0 + lj;
       double v = 0.0;
-      if (row < row_end && col < col_end && (!lower || lj <= li)) v = S[(size_t)row * ld + col];
+      if (row < row_end && col < col_end && (!lower || lj <= li))
+        v = coh ? gload<true>(&S[(size_t)row * ld + col]) : S[(size_t)row * ld + col];
       acc[nn][i] = v;
     }
 }
@@ -390,7 +391,7 @@ __device__ __forceinline__ void strip_update_tile(f64x4& acc, const lds_f64* Lr,
 }
 template <bool COH = false>
 __device__ __forceinline__ void frag_load_tile(f64x4& acc, const gbl_f64* __restrict__ S, int ld, int r0, int q0,
-                                               int rg, int nt, int row_end, int col_end, bool lower) {
+                                               int rg, int nt, int row_end, int col_end, bool lower, bool coh = false) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -398,7 +399,8 @@ __device__ __forceinline__ void frag_load_tile(f64x4& acc, const gbl_f64* __rest
     const int li = 16 * rg + g + 4 * i, lj = 16 * nt + r;
     const int row = r0 + li, col = q0 + lj;
     double v = 0.0;
-    if (row < row_end && col < col_end && (!lower || lj <= li)) v = gload<COH>(&S[(size_t)row * ld + col]);
+    if (row < row_end && col < col_end && (!lower || lj <= li))
+      v = (COH || coh) ? gload<true>(&S[(size_t)row * ld + col]) : gload<false>(&S[(size_t)row * ld + col]);
     acc[i] = v;
   }
 }
@@ -551,11 +553,14 @@ __device__ __forceinline__ void chol_strip_out(gbl_f64* __restrict__ S, int ld, 
   }
 }
 
+// coh_first (overlap mode, see chol_factor_persistent_kernel): the tile's own values were written by ANOTHER kernel
+// while this one was already running (no kernel-boundary invalidate in between), so this read of them must go past
+// the XCD's L2 (sc1); later reads see the workgroup's own write-through stores as before.
 template <bool PERSIST>
 __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld, int k, int bi, int bj,
                                           int* __restrict__ fail, double lm, double ep,
                                           gbl_f64* __restrict__ Ldiag, int* __restrict__ done,
-                                          int* __restrict__ abortf) {
+                                          int* __restrict__ abortf, bool coh_first = false) {
   lds_f64* const B0 = DROID_LDS(g_cholB0);      // L[bi,k]          (workgroup-local tiles, see their declaration)
   lds_f64* const B1 = DROID_LDS(g_cholB1);      // L[bj,k]
   lds_f64* const B2 = DROID_LDS(g_cholB2);      // the diagonal tile D -> L
@@ -589,7 +594,7 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
       return;
     }
     const int p0 = k * NB;
-    frag_load_global<2>(acc, S, ld, r0, q0, w4, 2 * grp, nrows, n, bi == bj);
+    frag_load_global<2>(acc, S, ld, r0, q0, w4, 2 * grp, nrows, n, bi == bj, coh_first);
     if (PERSIST && bj == kp + 1) {
       // tiles of the NEXT panel column take the two panel tiles strip by strip out of the hand-over slots, like
       // the panel workgroups do: their update ends right behind the last strip instead of a flag, an
@@ -657,7 +662,7 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
     if (i < ntile) {
       const int rg = (code[i] >> 2) & 3, nt = code[i] & 3;
       if (code[i] & 0x10) {
-        if (solve_rows) frag_load_tile(tacc[i], S, ld, r0, c0, rg, nt, nrows, n, diag);   // tile to solve
+        if (solve_rows) frag_load_tile(tacc[i], S, ld, r0, c0, rg, nt, nrows, n, diag, coh_first);   // tile to solve
       } else {
         frag_load_tile<PERSIST>(tacc[i], S, ld, c0, c0, rg, nt, c0 + wk, c0 + wk, true);   // diagonal tile
         if (k < 0 && rg == nt) {  // damping of block 0, applied to every workgroup's private copy
@@ -670,7 +675,7 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
   }
 #pragma unroll
   for (int i = 0; i < 3; i++)
-    if (i < ndef) frag_load_tile(dacc[i], S, ld, r0, c0, dg, (wave >= 5) ? i + 1 : wave, nrows, n, diag);
+    if (i < ndef) frag_load_tile(dacc[i], S, ld, r0, c0, dg, (wave >= 5) ? i + 1 : wave, nrows, n, diag, coh_first);
   if (!PERSIST && k >= 0) {
     if (grp == 0) load_tile64(B1, S, ld, c0, k * NB, c0, n, k * NB + NB, false, 0.0);
     else load_tile64(B0, S, ld, r0, k * NB, r0, nrows, k * NB + NB, false, 0.0);
@@ -959,14 +964,22 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
 __device__ __attribute__((noinline)) void chol_tile_persist(double* __restrict__ S, int n, int ld, int k, int bi,
                                                             int bj, int* __restrict__ fail, double lm, double ep,
                                                             double* __restrict__ Ldiag, int* __restrict__ done,
-                                                            int* __restrict__ abortf) {
-  chol_tile<true>((gbl_f64*)S, n, ld, k, bi, bj, fail, lm, ep, (gbl_f64*)Ldiag, done, abortf);
+                                                            int* __restrict__ abortf, bool coh_first) {
+  chol_tile<true>((gbl_f64*)S, n, ld, k, bi, bj, fail, lm, ep, (gbl_f64*)Ldiag, done, abortf, coh_first);
 }
 
+// OVERLAP mode (ready != nullptr; multi-GPU, SURVEY 8e / VERDICT r02 #6): the kernel is launched BEFORE the reduced
+// system is there.  The all-reduce of the packed system runs in row chunks on a side stream; each chunk is expanded
+// into S (damping applied there: pass lm = ep = 0 here) and then ready[block row] = epoch is published for its block
+// rows.  A tile (bi, bj) is first read by its owner at step -1 (column 0) or step 0 (all others): that read waits for
+// ready[bi] and goes past the L2 (sc1).  The diagonal chain reaches block row i after ~10.8 us x i while the rows up
+// to i are only (i / 24)^2 of the message, so after the first chunk the factorisation never waits for the collective.
+// The grid is capped below the CU count by the launcher, so the collective's and the unpack kernels always find CUs.
 __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __restrict__ S, int n, int ld,
                                                                      int* __restrict__ fail, double lm, double ep,
                                                                      int* __restrict__ flags,
-                                                                     double* __restrict__ Ldiag) {
+                                                                     double* __restrict__ Ldiag,
+                                                                     const int* __restrict__ ready, int epoch) {
   __shared__ int s_abort;
   const int nb = (n + NB - 1) / NB;       // block columns
   const int nrb = (n + 1 + NB - 1) / NB;  // block rows (row n = rhs)
@@ -982,7 +995,7 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
     for (int j = 0; j < nb; j++) {
       if (j >= 1 && (cs % G) == wg) {
         const int i = j * NB + t;
-        if (t < NB && i < n) {
+        if (ready == nullptr && t < NB && i < n) {   // (overlap mode: the rows are not there yet; damped by the unpack)
           const double d = S[(size_t)i * ld + i];
           gstore<true>((gbl_f64*)&S[(size_t)i * ld + i], d + (ep + lm * d));
         }
@@ -1011,28 +1024,33 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
       const bool panel = (bj == kp);
       // ---- wait for the inputs (wave 0: one flag per lane)
       PSTAMP(11);
+      const bool first_touch = (ready != nullptr) && (k <= 0);   // step -1: column 0; step 0: every other tile
       if (t < 64) {
         bool ok = true;
-        if (k >= 0) {
+        if (k >= 0 || first_touch) {
           // plain tile: both panel tiles complete (all four strips); panel tile: only the diagonal tile's
           // version here, the strips are awaited inside the body
           const int* p = nullptr;
           int need = 4 * k + 3;
-          const bool flagged = !panel && bj != kp + 1;  // tiles of the next panel column poll the hand-over slots
+          const bool flagged = k >= 0 && !panel && bj != kp + 1;  // tiles of the next panel column poll the hand-over slots
           if (t == 0 && flagged) p = &done[bi];
           else if (t == 1 && flagged && bj != bi) p = &done[bj];
-          else if (t == 2 && panel && bi != bj) { p = &dver[bj]; need = k; }
+          else if (t == 2 && k >= 0 && panel && bi != bj) { p = &dver[bj]; need = k; }
+          else if (t == 3 && first_touch) { p = &ready[bi]; need = epoch; }   // the tile's rows have been reduced
           bool sat = (p == nullptr);
           int spins = 0;
+          // overlap mode waits for the collective (and, when ranks share a GPU, for another rank's grid): seconds, not ms
+          const int limit = (ready != nullptr) ? (CFP_SPIN_LIMIT << 4) : CFP_SPIN_LIMIT;
           while (true) {
             if (!sat) sat = cfp_load(p) >= need;
             if (__all(sat)) break;
             spins++;
-            if (spins > CFP_SPIN_LIMIT || ((spins & 255) == 0 && __any(cfp_load(abortf) == 1))) {
+            if (spins > limit || ((spins & 255) == 0 && __any(cfp_load(abortf) == 1))) {
               ok = false;
               break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            if (ready != nullptr) __builtin_amdgcn_s_sleep(4);
+            else __builtin_amdgcn_s_sleep(1);
           }
         } else if (__any(cfp_load(abortf) == 1)) {
           ok = false;
@@ -1048,7 +1066,7 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
       PSTAMP(12);
       __syncthreads();  // also: the previous tile's LDS reads are over
       if (s_abort) return;
-      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf);
+      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf, first_touch);
       if (!panel && bi == bj) {  // publish the next version of a diagonal tile (panel tiles publish their strips)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's write-through stores are acknowledged
         __syncthreads();
@@ -1399,6 +1417,26 @@ static bool chol_cooperative() {
 }
 
 // returns true when the single-launch kernel ran (the back-substitution may then use what it left in `ldiag`)
+// Overlap mode: the single-launch kernel only (returns false when it cannot be used: the caller then unpacks the
+// whole system and solves the ordinary way).  `ready` [block rows] / `epoch`: see the kernel.  The grid leaves
+// `reserve` CUs free for the collective and the unpack kernels (DROID_OVERLAP_RESERVE_CUS, default 32).
+bool launch_chol_factor_overlap(double* sys, int n, int ld, int* fail_flag, int* flags, double* ldiag,
+                                const int* ready, int epoch, hipStream_t s) {
+  if (n <= 0 || !ready || chol_cooperative() || !chol_single_launch(sys, n, ld, flags, ldiag)) return false;
+  const int nb = (n + NB - 1) / NB, nrb = (n + 1 + NB - 1) / NB;
+  int total = 0;
+  for (int j = 0; j < nb; j++) total += nrb - j;
+  static const int reserve = getenv("DROID_OVERLAP_RESERVE_CUS") ? atoi(getenv("DROID_OVERLAP_RESERVE_CUS")) : 32;
+  int cap = chol_resident_workgroups() - (reserve > 0 ? reserve : 0);
+  if (cap < 8 || (size_t)total > (size_t)10 * cap) return false;
+  const int grid = total < cap ? total : cap;
+  auto lock = persist_enter(s);
+  const double zero = 0.0;
+  hipLaunchKernelGGL(chol_factor_persistent_kernel, dim3(grid), dim3(512), 0, s, sys, n, ld, fail_flag, zero, zero,
+                     flags, ldiag, ready, epoch);
+  return true;
+}
+
 bool launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* fail_flag, int* flags,
                         double* ldiag, hipStream_t s) {
   if (n <= 0) return false;
@@ -1413,13 +1451,15 @@ bool launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* f
     const int grid = total < cap ? total : cap;
     auto lock = persist_enter(s);
     if (chol_cooperative()) {
-      void* args[] = {&sys, &n, &ld, &fail_flag, &lm, &ep, &flags, &ldiag};
+      const int* no_ready = nullptr;
+      int no_epoch = 0;
+      void* args[] = {&sys, &n, &ld, &fail_flag, &lm, &ep, &flags, &ldiag, &no_ready, &no_epoch};
       if (hipLaunchCooperativeKernel((const void*)chol_factor_persistent_kernel, dim3(grid), dim3(512), args, 0, s) == hipSuccess)
         return true;
       (void)hipGetLastError();  // refused (grid cannot be resident now): per-step kernels below
     } else {
       hipLaunchKernelGGL(chol_factor_persistent_kernel, dim3(grid), dim3(512), 0, s, sys, n, ld, fail_flag, lm,
-                         ep, flags, ldiag);
+                         ep, flags, ldiag, (const int*)nullptr, 0);
       return true;
     }
   }

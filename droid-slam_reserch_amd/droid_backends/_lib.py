@@ -20,6 +20,7 @@ SYMBOLS = [
     "droid_altcorr_pyramid_forward_f16",
     "droid_ba_workspace_bytes", "droid_ba", "droid_ba_prepare", "droid_ba_build", "droid_ba_build_packed",
     "droid_ba_packed_system", "droid_ba_unpack_system",
+    "droid_ba_overlap_plan", "droid_ba_unpack_chunk", "droid_ba_solve_update_overlap",
     "droid_ba_solve_update", "droid_ba_profile_iteration", "droid_ba_system", "droid_ba_status",
     "droid_ba_attach_status_mirror", "droid_chol_solve", "droid_chol_scratch_doubles", "droid_reproject_motion",
     "droid_frame_distance", "droid_frame_distance_matrix", "droid_projmap", "droid_iproj", "droid_depth_filter",
@@ -68,6 +69,9 @@ def load() -> ctypes.CDLL:
     lib.droid_ba_packed_system.restype = vp
     lib.droid_ba_unpack_system.argtypes = [c_int] * 8 + [vp, sz, vp]
     lib.droid_ba_solve_update.argtypes = [vp] * 6 + [c_int] * 7 + [c_float, c_float, c_int, vp, vp, vp, sz, vp]
+    lib.droid_ba_overlap_plan.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(sz)]
+    lib.droid_ba_unpack_chunk.argtypes = [c_int] * 9 + [c_float, c_float, c_int, vp, sz, vp]
+    lib.droid_ba_solve_update_overlap.argtypes = [vp] * 6 + [c_int] * 9 + [vp, vp, vp, sz, vp]
     lib.droid_ba_profile_iteration.argtypes = [vp] * 9 + [c_int] * 7 + [c_float, c_float, c_int, vp, sz, vp, vp]
     lib.droid_ba_system.argtypes = [vp] + [c_int] * 7 + [ctypes.POINTER(sz)]
     lib.droid_ba_system.restype = vp

@@ -148,6 +148,40 @@ class HipBackend:
                                                   self.ws.numel(), s), "ba_solve_update")
         return self.dx
 
+    # ---- overlap of the collective with the solve (opt-in: ShardedBA(overlap=True)) ----------------------------
+    OVERLAP_MAX_CHUNKS = 8
+
+    def overlap_plan(self):
+        """[(first, last)] element ranges of `self.packed`, one per chunk (whole block rows of the system, in order)."""
+        E, nbuf, H, W, M, t0, t1 = self._dims
+        nc = ctypes.c_int(0)
+        offs = (ctypes.c_size_t * (self.OVERLAP_MAX_CHUNKS + 1))()
+        _lib.check(self.lib.droid_ba_overlap_plan(t0, t1, self.OVERLAP_MAX_CHUNKS, ctypes.byref(nc), offs), "ba_overlap_plan")
+        return [(int(offs[c]), int(offs[c + 1])) for c in range(nc.value)]
+
+    def unpack_chunk(self, chunk, lm, ep, epoch):
+        """Chunk `chunk` of the (all-reduced) packed system -> pitched matrix, damped, then published for `epoch`;
+        on the current stream (the side stream of the overlap)."""
+        E, nbuf, H, W, M, t0, t1 = self._dims
+        _lib.check(self.lib.droid_ba_unpack_chunk(E, nbuf, H, W, M, t0, t1, int(chunk), self.OVERLAP_MAX_CHUNKS, float(lm),
+                                                  float(ep), int(epoch), self.ws.data_ptr(), self.ws.numel(),
+                                                  torch.cuda.current_stream().cuda_stream), "ba_unpack_chunk")
+
+    def solve_update_overlap(self, p: BAProblemDev, epoch, motion_only):
+        """Launches the solve of iteration `epoch` BEFORE its system has been reduced: the factorisation waits for the
+        block rows it is about to read.  Returns False when the single-launch solver cannot take this system."""
+        E, nbuf, H, W, M, t0, t1 = self._dims
+        s = torch.cuda.current_stream().cuda_stream
+        rc = self.lib.droid_ba_solve_update_overlap(p.poses.data_ptr(), p.disps.data_ptr(), p.intrinsics.data_ptr(),
+                                                    p.weights.data_ptr(), p.ii.data_ptr(), p.jj.data_ptr(), E, nbuf, H, W, M,
+                                                    t0, t1, int(epoch), int(motion_only), self.dx.data_ptr(),
+                                                    self.dz.data_ptr() if M > 0 else None, self.ws.data_ptr(),
+                                                    self.ws.numel(), s)
+        if rc == -1:      # DROID_E_ARG: not available for this system
+            return False
+        _lib.check(rc, "ba_solve_update_overlap")
+        return True
+
     def profile_iteration(self, p: BAProblemDev, lm, ep, motion_only):
         """Stage times in ms of one iteration (measurement support, synchronises)."""
         E, nbuf, H, W, M, t0, t1 = self._dims
@@ -172,9 +206,16 @@ class ShardedBA:
     """`iterations` Gauss-Newton steps over an edge-sharded graph.  world_size 1 degenerates to
     the single-GPU path (no collective is issued)."""
 
-    def __init__(self, backend=None, group=None):
+    def __init__(self, backend=None, group=None, overlap=None):
+        """overlap: all-reduce the packed system in row chunks on a side stream while the factorisation, launched
+        first, already works on the leading block rows (include/droid_backends_hip.h, droid_ba_overlap_plan).  Opt-in
+        (default: the environment variable DROID_BA_OVERLAP=1): rehearsed with gloo and in-process shards, not yet
+        measured over RCCL."""
+        import os
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
+        self.overlap = (os.environ.get("DROID_BA_OVERLAP", "0") == "1") if overlap is None else bool(overlap)
+        self._side = None
 
     def _world(self):
         import torch.distributed as dist
@@ -189,7 +230,29 @@ class ShardedBA:
         own = (0, nbuf) if own is None else own
         be = self.backend
         be.prepare(p, t0, t1, own, motion_only)
-        for _ in range(int(iterations)):
+        use_overlap = self.overlap and world > 1 and hasattr(be, "solve_update_overlap") and not motion_only \
+            and int(p.ii.shape[0]) > 0
+        for it in range(int(iterations)):
+            if use_overlap:
+                packed = be.build_packed(p, motion_only)
+                main = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                built = torch.cuda.Event()
+                built.record(main)
+                if be.solve_update_overlap(p, it + 1, motion_only):      # main stream: waits chunk by chunk on the device
+                    with torch.cuda.stream(self._side):
+                        self._side.wait_event(built)
+                        for c, (a, b) in enumerate(be.overlap_plan()):
+                            dist.all_reduce(packed[a:b], op=dist.ReduceOp.SUM, group=self.group)
+                            be.unpack_chunk(c, lm, ep, it + 1)
+                    main.wait_stream(self._side)     # the next build clears the packed system
+                    continue
+                use_overlap = False                                      # system too small / solver mode: ordinary path
+                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+                be.unpack(motion_only)
+                be.solve_update(p, lm, ep, motion_only)
+                continue
             if world > 1 and hasattr(be, "build_packed"):
                 # the build kernels add straight into the packed triangle: one collective on a contiguous tensor,
                 # then ONE extra launch (unpack) in front of the solve -- no gather / scatter of the triangle

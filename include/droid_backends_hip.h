@@ -163,6 +163,27 @@ double *droid_ba_packed_system(void *workspace, int E, int nbuf, int H, int W, i
 int droid_ba_unpack_system(int E, int nbuf, int H, int W, int M, int t0, int t1, int motion_only,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* Overlap of the collective with the solve (multi-GPU, opt-in).  The factorisation consumes
+ * the system top-left to bottom-right and the packed system is row-major, so a PREFIX of it is all the leading block
+ * rows need.  droid_ba_overlap_plan cuts the packed tensor into at most max_chunks contiguous element ranges
+ * [packed_offsets[c], packed_offsets[c+1]) by block rows of 64 (2, 3, 4, 5, 5, ... block rows).  Per iteration:
+ *   main stream : droid_ba_build_packed ... droid_ba_solve_update_overlap(epoch)   -- launched BEFORE the reduction;
+ *                 its factorisation waits, tile by tile, for the block rows it is about to read
+ *   side stream : (after the build) for c = 0 .. nchunks-1: all-reduce chunk c of the packed tensor in place, then
+ *                 droid_ba_unpack_chunk(c, lm, ep, epoch): rows -> pitched matrix with the damping applied, then the
+ *                 block rows are published for `epoch`.
+ * epoch = 1, 2, ... within one droid_ba_prepare (which resets the published epochs).  The spinning grid leaves
+ * DROID_OVERLAP_RESERVE_CUS (default 32) compute units free for the collective's kernels.  Returns DROID_E_ARG
+ * when the single-launch solver cannot run this system (then: droid_ba_unpack_system + droid_ba_solve_update).
+ * Rehearsed with two ranks on one GPU (gloo) and with eight in-process shards; NOT yet measured over RCCL. */
+int droid_ba_overlap_plan(int t0, int t1, int max_chunks, int *nchunks_out, size_t *packed_offsets);
+int droid_ba_unpack_chunk(int E, int nbuf, int H, int W, int M, int t0, int t1, int chunk, int max_chunks, float lm,
+                          float ep, int epoch, void *workspace, size_t workspace_bytes, void *stream);
+int droid_ba_solve_update_overlap(float *poses, float *disps, const float *intrinsics, const float *weights,
+                                  const int64_t *ii, const int64_t *jj, int E, int nbuf, int H, int W, int M,
+                                  int t0, int t1, int epoch, int motion_only, float *dx_out, float *dz_out,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+
 int droid_ba_solve_update(float *poses, float *disps, const float *intrinsics, const float *weights,
                           const int64_t *ii, const int64_t *jj, int E, int nbuf, int H, int W, int M,
                           int t0, int t1, float lm, float ep, int motion_only, float *dx_out,
