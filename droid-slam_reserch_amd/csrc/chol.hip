@@ -975,6 +975,12 @@ __device__ __attribute__((noinline)) void chol_tile_persist(double* __restrict__
 // ready[bi] and goes past the L2 (sc1).  The diagonal chain reaches block row i after ~10.8 us x i while the rows up
 // to i are only (i / 24)^2 of the message, so after the first chunk the factorisation never waits for the collective.
 // The grid is capped below the CU count by the launcher, so the collective's and the unpack kernels always find CUs.
+#ifdef OV_DEBUG
+__device__ unsigned long long g_ov_dbg[64];
+extern "C" int droid_debug_overlap_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ov_dbg), sizeof(unsigned long long) * 64);
+}
+#endif
 __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __restrict__ S, int n, int ld,
                                                                      int* __restrict__ fail, double lm, double ep,
                                                                      int* __restrict__ flags,
@@ -1004,6 +1010,107 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
         if (t == 0) cfp_store(&dver[j], 0);
       }
       cs += nrb - j;
+    }
+  }
+
+#ifdef OV_DEBUG
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_ov_dbg[63] = wall_clock64();
+#endif
+  if (ready != nullptr) {
+    // ---- overlap mode: per-tile progress instead of the step-major walk below.  A workgroup owns up to a handful of
+    // tiles; stepping them in lockstep would park it at step 0 on a tile whose block row arrives with the LAST chunk
+    // of the collective while its other tile sits on the chain.  Here every owned tile keeps its own next step; wave 0
+    // scans them in ownership order (earlier block columns first), takes the first whose inputs are there -- the same
+    // flags as below, polled once instead of waited for, plus ready[bi] at the tile's first step -- and spins
+    // (bounded) only when none is.  Dependencies only point to earlier block columns, so skipping a waiting tile can
+    // never starve the tile that is picked.
+    constexpr int MAXT = 12;   // the launcher admits at most 10 tiles per workgroup
+    __shared__ int s_ti[MAXT], s_tj[MAXT], s_nx[MAXT], s_nt, s_pick;
+    if (t == 0) {
+      int nt = 0, cj = 0, cs = 0;
+      for (int idx = wg; idx < total && nt < MAXT; idx += G) {
+        while (idx >= cs + (nrb - cj)) {
+          cs += nrb - cj;
+          cj++;
+        }
+        s_ti[nt] = cj + (idx - cs);
+        s_tj[nt] = cj;
+        s_nx[nt] = (cj == 0) ? -1 : 0;     // column 0 has the initial panel step only
+        nt++;
+      }
+      s_nt = nt;
+    }
+    __syncthreads();
+    while (true) {
+      if (t < 64) {
+        int pick = -1, spins = 0;
+        bool ok = true;
+        const int nt = s_nt;
+        while (true) {
+          bool any_left = false;
+          for (int i = 0; i < nt; i++) {
+            const int bi = s_ti[i], bj = s_tj[i], k = s_nx[i];
+            if (k > bj - 1) continue;      // this tile is final (last step: its panel step k = bj - 1)
+            any_left = true;
+            const int kp = k + 1;
+            const bool panel = (bj == kp);
+            const bool first = (k == ((bj == 0) ? -1 : 0));
+            const int* p = nullptr;
+            int need = 4 * k + 3;
+            const bool flagged = k >= 0 && !panel && bj != kp + 1;
+            if (t == 0 && flagged) p = &done[bi];
+            else if (t == 1 && flagged && bj != bi) p = &done[bj];
+            else if (t == 2 && k >= 0 && panel && bi != bj) { p = &dver[bj]; need = k; }
+            else if (t == 3 && first) p = &ready[bi], need = epoch;
+            bool sat = (p == nullptr) || cfp_load(p) >= need;
+            // Panel tiles and tiles of the next panel column take their two panel tiles strip by strip out of the
+            // hand-over slots INSIDE the body, and wait there: enter only once the producers have started writing
+            // (first strip of each slot no longer carries the preset tag) -- a producer in a block row that comes
+            // with a late chunk would otherwise park this workgroup, and its other tiles with it.
+            if ((t == 4 || t == 5) && k >= 0 && (panel || bj == kp + 1)) {
+              const int r = (t == 4) ? bi : (panel ? kp : bj);
+              const gbl_f64* sl = (const gbl_f64*)Ldiag + chol_lfin_offset(n) + (size_t)chol_tile_index(nrb, r, k) * NB * NB;
+              sat = __double_as_longlong(gload<true>(sl)) != CFP_TAG;
+            }
+            if (__all(sat)) {
+              pick = i;
+              break;
+            }
+          }
+          if (!any_left) pick = -2;
+          if (pick != -1) break;
+          if (++spins > (CFP_SPIN_LIMIT << 2) || ((spins & 63) == 0 && __any(cfp_load(abortf) == 1))) {
+            ok = false;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(4);
+        }
+        if (t == 0) {
+          s_pick = ok ? pick : -3;
+          if (!ok) {
+            cfp_store(abortf, 1);
+            atomicMax(fail, 2);
+          }
+        }
+      }
+      __syncthreads();  // also: the previous tile's LDS reads are over
+      const int pick = s_pick;
+      if (pick < 0) return;   // -2: every owned tile is final; -3: stalled (reported)
+      const int bi = __builtin_amdgcn_readfirstlane(s_ti[pick]), bj = __builtin_amdgcn_readfirstlane(s_tj[pick]);
+      const int k = __builtin_amdgcn_readfirstlane(s_nx[pick]);
+      const bool first = (k == ((bj == 0) ? -1 : 0));
+      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf, first);
+#ifdef OV_DEBUG
+      if (t == 0 && bi == bj && bj == k + 1 && bj < 62) g_ov_dbg[bj] = wall_clock64();   // diagonal tile of column bj factored
+#endif
+      if (bj != k + 1 && bi == bj) {  // publish the next version of a diagonal tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) cfp_store(&dver[bj], k + 1);
+      }
+      __syncthreads();
+      if (t == 0) s_nx[pick] = k + 1;
+      __syncthreads();
     }
   }
 
