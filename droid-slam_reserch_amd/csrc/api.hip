@@ -215,7 +215,7 @@ int droid_ba_prepare(const int64_t* ii, const int64_t* jj, int E, int nbuf, int 
   v.motion_only = motion_only ? 1 : 0;
   launch_prep(v, ii, jj, (hipStream_t)stream);
   // overlap mode: no reduced rows of any iteration of this call are in `sys` yet (epochs start at 1)
-  (void)hipMemsetAsync(v.ov_ready, 0, sizeof(int) * ((size_t)(v.n + 1 + CHOL_NB - 1) / CHOL_NB), (hipStream_t)stream);
+  (void)hipMemsetAsync(v.ov_ready, 0, sizeof(int) * ((size_t)(v.n + 1 + CHOL_NB - 1) / CHOL_NB), (hipStream_t)stream);   // (>= block columns)
   return check_hip("ba_prepare");
 }
 
@@ -261,7 +261,7 @@ double* droid_ba_packed_system(void* workspace, int E, int nbuf, int H, int W, i
   BaView v;
   if (!workspace || t1 <= t0) return nullptr;
   ba_carve(v, workspace, E, nbuf, H, W, t0, t1, M);
-  if (n_elements) *n_elements = packed_offset(v.n + 1);
+  if (n_elements) *n_elements = pk_total(v.n);
   return v.psys;
 }
 
@@ -275,16 +275,17 @@ int droid_ba_unpack_system(int E, int nbuf, int H, int W, int M, int t0, int t1,
 }
 
 // ---- overlap of the all-reduce with the solve (multi-GPU) ------------------------------------------------------
-// Row chunks of the packed system by block rows of 64: 2, 3, 4, 5, 5, ... block rows -- the first chunk small
-// (the factorisation starts on it), the later ones larger (they arrive long before the diagonal chain reaches them).
-static int overlap_bounds(int n, int max_chunks, int* brow /*[max_chunks + 1]*/) {
-  const int nrb = (n + 1 + CHOL_NB - 1) / CHOL_NB;
-  int nc = 0, b = 0, size = 2;
-  brow[0] = 0;
-  while (b < nrb && nc < max_chunks) {
-    b = (nc + 1 == max_chunks || b + size >= nrb) ? nrb : b + size;
-    brow[++nc] = b;
-    if (size < 5) size++;
+// Chunks of the packed system by block columns of 64: 1, 1, 2, 3, 4, 5, ... block columns.  The first ones are
+// small in columns (a block column on the left is the tallest: column 0 alone is 8 % of the bytes) because the
+// factorisation starts on them; the later, larger chunks arrive long before the diagonal chain reaches their columns.
+static int overlap_bounds(int n, int max_chunks, int* bcol /*[max_chunks + 1]*/) {
+  const int nb = (n + CHOL_NB - 1) / CHOL_NB;
+  int nc = 0, b = 0, size = 1, ones = 0;
+  bcol[0] = 0;
+  while (b < nb && nc < max_chunks) {
+    b = (nc + 1 == max_chunks || b + size >= nb) ? nb : b + size;
+    bcol[++nc] = b;
+    if (++ones >= 2) size++;
   }
   return nc;
 }
@@ -295,7 +296,8 @@ int droid_ba_overlap_plan(int t0, int t1, int max_chunks, int* nchunks_out, size
   const int n = 6 * (t1 - t0);
   int brow[33];
   const int nc = overlap_bounds(n, max_chunks, brow);
-  for (int c = 0; c <= nc; c++) packed_offsets[c] = packed_offset(std::min(CHOL_NB * brow[c], n + 1));
+  const int nb = (n + CHOL_NB - 1) / CHOL_NB;
+  for (int c = 0; c <= nc; c++) packed_offsets[c] = brow[c] >= nb ? pk_total(n) : pk_colbase(n, brow[c]);
   *nchunks_out = nc;
   return DROID_OK;
 }
@@ -309,8 +311,7 @@ int droid_ba_unpack_chunk(int E, int nbuf, int H, int W, int M, int t0, int t1, 
   if (max_chunks < 1 || max_chunks > 32) return fail(DROID_E_ARG, "ba_unpack_chunk: bad %s", "max_chunks");
   const int nc = overlap_bounds(v.n, max_chunks, brow);
   if (chunk < 0 || chunk >= nc || epoch <= 0) return fail(DROID_E_ARG, "ba_unpack_chunk: bad %s", "chunk / epoch");
-  const int row0 = std::min(CHOL_NB * brow[chunk], v.n + 1), row1 = std::min(CHOL_NB * brow[chunk + 1], v.n + 1);
-  launch_unpack_rows(v, row0, row1, (double)lm, (double)ep, brow[chunk], brow[chunk + 1], epoch, (hipStream_t)stream);
+  launch_unpack_cols(v, brow[chunk], brow[chunk + 1], (double)lm, (double)ep, epoch, (hipStream_t)stream);
   return check_hip("ba_unpack_chunk");
 }
 

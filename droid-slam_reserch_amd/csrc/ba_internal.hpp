@@ -34,11 +34,23 @@ __host__ __device__ inline size_t chol_mbuf_offset(int n) { return ((size_t)(n +
 __host__ __device__ inline size_t chol_lfin_offset(int n) { return 2 * chol_mbuf_offset(n); }
 __host__ __device__ inline size_t chol_ldiag_doubles(int n) { return chol_lfin_offset(n) + chol_tiles(n) * CHOL_NB * CHOL_NB; }
 
-// Packed lower triangle + rhs row: row i holds columns 0..i in (i + 2) & ~1 doubles (16-byte aligned rows);
-// row n = rhs.  packed_offset(i) = sum of the lengths of rows < i; packed_offset(n + 1) = total.
-__host__ __device__ inline size_t packed_offset(int i) {
-  const size_t m = (size_t)(i >> 1);
-  return 2 * m * (m + 1) + ((i & 1) ? 2 * m + 2 : 0);
+// Packed lower triangle + rhs row, BLOCK-COLUMN major (what the ranks all-reduce): block column J = columns
+// 64 J .. 64 J + w_J - 1 (w_J = 64, the last one n - 64 J) holds rows 64 J .. n (row n = rhs) as rows of w_J doubles.
+// The factorisation consumes block columns left to right, so a PREFIX of this tensor is all its first block columns
+// need: the collective can be cut into column chunks that arrive in the order the solver wants them (overlap mode).
+// (The strict upper halves of the diagonal tiles are carried along as zeros: 4 % of the bytes.)
+__host__ __device__ inline size_t pk_colbase(int n, int J) {
+  return (size_t)CHOL_NB * ((size_t)J * (size_t)(n + 1) - (size_t)CHOL_NB * (size_t)J * (size_t)(J - 1) / 2);
+}
+__host__ __device__ inline int pk_width(int n, int J) { return (n - CHOL_NB * J) < CHOL_NB ? (n - CHOL_NB * J) : CHOL_NB; }
+__host__ __device__ inline size_t pk_total(int n) {
+  if (n <= 0) return 0;
+  const int nb = (n + CHOL_NB - 1) / CHOL_NB;
+  return pk_colbase(n, nb - 1) + (size_t)(n + 1 - CHOL_NB * (nb - 1)) * (size_t)pk_width(n, nb - 1);
+}
+__host__ __device__ inline size_t pk_index(int n, int gi, int gj) {   // gi >= 64 (gj / 64); gi = n: rhs row
+  const int J = gj / CHOL_NB;
+  return pk_colbase(n, J) + (size_t)(gi - CHOL_NB * J) * (size_t)pk_width(n, J) + (size_t)(gj - CHOL_NB * J);
 }
 
 enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4,
@@ -80,14 +92,14 @@ struct BaView {
   int zsplit;              // linearisation: workgroups per (slot, pixel chunk), each takes a range of the slot's edges
   float* zpart;            // zsplit > 1: [zsplit][M][8][HW] partial C, w and self-row sums of those workgroups
   double* sys;             // [n+1][ld] reduced camera system, lower triangle, row n = rhs
-  double* psys;            // the same entries packed (rows of i+1 values rounded up to even, then the rhs row):
-                           // what a rank's build phase accumulates into when the systems are all-reduced
+  double* psys;            // the same entries packed block-column major (pk_index): what a rank's build phase
+                           // accumulates into when the systems are all-reduced
   int packed;              // 1: the build kernels add into psys (multi-GPU), 0: straight into sys
   double* xsol;            // [ld] solve scratch / solution
   float* dx;               // [P][6]
   int* bs_flags;           // [chol_flag_words(n)] hand-off flags of the single-launch factorisation
   double* ldiag;           // [ceil(n/64)][64][64] factored diagonal tiles, then the hand-over slots of the panel tiles
-  int* ov_ready;           // [block rows of the system] overlap mode: epoch of the last iteration whose reduced rows are in `sys`
+  int* ov_ready;           // [block columns of the system] overlap mode: epoch of the last iteration whose reduced columns are in `sys`
 };
 
 struct BaSizes {
@@ -152,7 +164,7 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
     v.Gpart = static_cast<double*>(take(sizeof(double) * (tiles * v.s2_split * 256 + 64)));
   }
   v.sys = static_cast<double*>(take(sizeof(double) * ((size_t)(v.n + 1) * v.ld + 8)));
-  v.psys = static_cast<double*>(take(sizeof(double) * (packed_offset(v.n + 1) + 8)));
+  v.psys = static_cast<double*>(take(sizeof(double) * (pk_total(v.n) + 8)));
   v.packed = 0;
   v.xsol = static_cast<double*>(take(sizeof(double) * ((size_t)v.ld + 1)));
   v.bs_flags = static_cast<int*>(take(sizeof(int) * chol_flag_words(v.n)));   // directly after xsol: one fill presets both
@@ -195,9 +207,9 @@ void launch_update(const BaView& v, float* poses, float* disps, const float* int
 void launch_chol_solve(double* sys, int n, int ld, double lm, double ep, double* x, int* fail_flag,
                        int* flags, double* ldiag, hipStream_t s, bool preset_done = false);
 
-// Overlap mode (multi-GPU): rows [row0, row1) of the all-reduced packed system -> pitched matrix, damped; then
-// ready[block rows b0..b1) = epoch for the factorisation that is already running (launch_chol_factor_overlap).
-void launch_unpack_rows(const BaView& v, int row0, int row1, double lm, double ep, int b0, int b1, int epoch, hipStream_t s);
+// Overlap mode (multi-GPU): block columns [J0, J1) of the all-reduced packed system -> pitched matrix, damped; then
+// ready[J0..J1) = epoch for the factorisation that is already running (launch_chol_factor_overlap).
+void launch_unpack_cols(const BaView& v, int J0, int J1, double lm, double ep, int epoch, hipStream_t s);
 bool launch_chol_factor_overlap(double* sys, int n, int ld, int* fail_flag, int* flags, double* ldiag,
                                 const int* ready, int epoch, hipStream_t s);
 // launch_chol_factor returns whether the single-launch kernel ran; pass that to launch_chol_backsolve

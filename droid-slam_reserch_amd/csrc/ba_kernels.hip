@@ -113,7 +113,7 @@ __device__ __forceinline__ int reduce32_index(int lane) {
 
 // Address of entry (gi, gj), gj <= gi, of the reduced camera system (row n = rhs) for the build kernels' atomics
 __device__ __forceinline__ double* sys_at(const BaView& v, int gi, int gj) {
-  return v.packed ? v.psys + packed_offset(gi) + gj : v.sys + (size_t)gi * v.ld + gj;
+  return v.packed ? v.psys + pk_index(v.n, gi, gj) : v.sys + (size_t)gi * v.ld + gj;
 }
 
 // Per-edge metadata of one depth slot, resident in LDS for the lifetime of a workgroup, so that
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(LIN_THREADS, 3) void ba_lin_kernel(
     const int nz = (int)gridDim.x - zero_base;
     if (v.packed) {
       double2* p = reinterpret_cast<double2*>(v.psys);
-      const size_t n2 = packed_offset(v.n + 1) / 2;
+      const size_t n2 = pk_total(v.n) / 2;
       for (size_t c = (size_t)((int)blockIdx.x - zero_base) * LIN_THREADS + tid; c < n2; c += (size_t)nz * LIN_THREADS)
         p[c] = make_double2(0.0, 0.0);
       return;
@@ -1849,34 +1849,27 @@ __global__ void ba_pose_retr_kernel(BaView v, float* __restrict__ poses, const d
   for (int n = 0; n < 4; n++) poses[7 * k + 3 + n] = qn[n];
 }
 
-// multi-GPU: psys (packed, all-reduced over the ranks) -> sys (pitched, what the solver factors in place)
-__global__ __launch_bounds__(256) void ba_unpack_kernel(BaView v) {
-  for (int row = blockIdx.x; row <= v.n; row += gridDim.x) {
-    const double2* src = reinterpret_cast<const double2*>(v.psys + packed_offset(row));
-    double2* dst = reinterpret_cast<double2*>(v.sys + (size_t)row * v.ld);
-    const int n2 = (row == v.n) ? (v.n + 1) / 2 : (row + 2) / 2;
-    for (int c = threadIdx.x; c < n2; c += 256) dst[c] = src[c];
-  }
-}
-
-// overlap mode: a chunk of rows, with the damping diag += ep + lm diag (dk:1197) the factorisation would apply --
-// it is already running and must not touch rows that are not there yet
-__global__ __launch_bounds__(256) void ba_unpack_rows_kernel(BaView v, int row0, int row1, double lm, double ep) {
-  for (int row = row0 + blockIdx.x; row < row1; row += gridDim.x) {
-    const double2* src = reinterpret_cast<const double2*>(v.psys + packed_offset(row));
-    double2* dst = reinterpret_cast<double2*>(v.sys + (size_t)row * v.ld);
-    const int n2 = (row == v.n) ? (v.n + 1) / 2 : (row + 2) / 2;
-    for (int c = threadIdx.x; c < n2; c += 256) {
-      double2 x = src[c];
-      if (row < v.n && (row >> 1) == c) {
-        if (row & 1) x.y += ep + lm * x.y;
-        else x.x += ep + lm * x.x;
+// multi-GPU: psys (packed block-column major, all-reduced over the ranks) -> sys (pitched, what the solver factors in
+// place).  grid (rows, block columns J0..J1-1); DAMP (overlap mode): diag += ep + lm diag (dk:1197) here, because the
+// factorisation is already running and must not touch columns that are not there yet.
+// 256 threads = 8 rows x 32 16-byte units (w_J is even; the strict upper halves of the diagonal tiles are zeros in
+// the packed tensor and unread in the pitched one, so whole rows are copied).
+template <bool DAMP>
+__global__ __launch_bounds__(256) void ba_unpack_kernel(BaView v, int J0, double lm, double ep) {
+  const int J = J0 + (int)blockIdx.y, w = pk_width(v.n, J), c0 = CHOL_NB * J;
+  const int c = 2 * ((int)threadIdx.x & 31);
+  for (int row = c0 + 8 * (int)blockIdx.x + ((int)threadIdx.x >> 5); row <= v.n; row += 8 * (int)gridDim.x) {
+    if (c < w) {
+      double2 x = *reinterpret_cast<const double2*>(v.psys + pk_colbase(v.n, J) + (size_t)(row - c0) * w + c);
+      if (DAMP && row < v.n) {
+        if (c0 + c == row) x.x += ep + lm * x.x;
+        else if (c0 + c + 1 == row) x.y += ep + lm * x.y;
       }
-      dst[c] = x;
+      *reinterpret_cast<double2*>(v.sys + (size_t)row * v.ld + c0 + c) = x;
     }
   }
 }
-// runs behind ba_unpack_rows_kernel in stream order: its rows are in memory (end-of-kernel release)
+// runs behind the unpack in stream order: its columns are in memory (end-of-kernel release)
 __global__ void ba_set_ready_kernel(int* __restrict__ ready, int b0, int b1, int epoch) {
   const int b = b0 + (int)threadIdx.x;
   if (b < b1) __hip_atomic_store(ready + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1886,12 +1879,15 @@ __global__ void ba_set_ready_kernel(int* __restrict__ ready, int b0, int b1, int
 // host-side launchers
 // ------------------------------------------------------------------------------------------
 void launch_unpack_system(const BaView& v, hipStream_t s) {
-  if (v.n > 0) hipLaunchKernelGGL(ba_unpack_kernel, dim3(min(v.n + 1, 1024)), dim3(256), 0, s, v);
+  if (v.n <= 0) return;
+  const int nb = (v.n + CHOL_NB - 1) / CHOL_NB;
+  hipLaunchKernelGGL(ba_unpack_kernel<false>, dim3(min((v.n + 8) / 8, 64), nb), dim3(256), 0, s, v, 0, 0.0, 0.0);
 }
 
-void launch_unpack_rows(const BaView& v, int row0, int row1, double lm, double ep, int b0, int b1, int epoch, hipStream_t s) {
-  if (row1 > row0) hipLaunchKernelGGL(ba_unpack_rows_kernel, dim3(min(row1 - row0, 256)), dim3(256), 0, s, v, row0, row1, lm, ep);
-  if (b1 > b0) hipLaunchKernelGGL(ba_set_ready_kernel, dim3(1), dim3(64), 0, s, v.ov_ready, b0, b1, epoch);
+void launch_unpack_cols(const BaView& v, int J0, int J1, double lm, double ep, int epoch, hipStream_t s) {
+  if (J1 <= J0) return;
+  hipLaunchKernelGGL(ba_unpack_kernel<true>, dim3(min((v.n + 8 - CHOL_NB * J0) / 8, 64), J1 - J0), dim3(256), 0, s, v, J0, lm, ep);
+  hipLaunchKernelGGL(ba_set_ready_kernel, dim3(1), dim3(64), 0, s, v.ov_ready, J0, J1, epoch);
 }
 
 void launch_prep(const BaView& v, const int64_t* ii, const int64_t* jj, hipStream_t s) {
@@ -1932,7 +1928,7 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
         hipLaunchKernelGGL((ba_lin_kernel<false, false, false>), dim3(v.E + ZB, v.nch), dim3(LIN_THREADS), 0, s, v, poses,
                            disps, intr, sens, targets, weights, eta, ii, jj, v.E);
       } else {
-        if (v.packed) (void)hipMemsetAsync(v.psys, 0, sizeof(double) * packed_offset(v.n + 1), s);
+        if (v.packed) (void)hipMemsetAsync(v.psys, 0, sizeof(double) * pk_total(v.n), s);
         else (void)hipMemsetAsync(v.sys, 0, sizeof(double) * (size_t)(v.n + 1) * v.ld, s);
       }
       break;

@@ -560,7 +560,7 @@ template <bool PERSIST>
 __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld, int k, int bi, int bj,
                                           int* __restrict__ fail, double lm, double ep,
                                           gbl_f64* __restrict__ Ldiag, int* __restrict__ done,
-                                          int* __restrict__ abortf, bool coh_first = false) {
+                                          int* __restrict__ abortf, bool coh_first = false, int k_last = -2) {
   lds_f64* const B0 = DROID_LDS(g_cholB0);      // L[bi,k]          (workgroup-local tiles, see their declaration)
   lds_f64* const B1 = DROID_LDS(g_cholB1);      // L[bj,k]
   lds_f64* const B2 = DROID_LDS(g_cholB2);      // the diagonal tile D -> L
@@ -612,10 +612,18 @@ __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld
           block_update16(acc[nn], &B0[(16 * w4) * LDP + 16 * sp], &Bx[(16 * (2 * grp + nn)) * LDP + 16 * sp]);
       }
     } else {
-    if (grp == 0) load_tile64<PERSIST>(B0, S, ld, r0, p0, r0, nrows, p0 + NB, false, 0.0);
-    else if (bi != bj) load_tile64<PERSIST>(B1, S, ld, q0, p0, q0, n, p0 + NB, false, 0.0);
-    __syncthreads();
-    strip_update<2>(acc, B0, (bi == bj) ? B0 : B1, w4, 2 * grp);
+    // k_last > k (overlap mode): a tile whose block column arrived late REPLAYS the updates of all block columns k..k_last
+    // that are final by now in one go -- tile loaded once, one pair of panel tiles per column, stored once (2-3 us per
+    // column instead of the 12 us of a full scheduler step)
+    const int klast = (k_last > k) ? k_last : k;
+    for (int kk = k; kk <= klast; kk++) {
+      const int pk = kk * NB;
+      if (kk > k) __syncthreads();   // the previous column's operand reads are over
+      if (grp == 0) load_tile64<PERSIST>(B0, S, ld, r0, pk, r0, nrows, pk + NB, false, 0.0);
+      else if (bi != bj) load_tile64<PERSIST>(B1, S, ld, q0, pk, q0, n, pk + NB, false, 0.0);
+      __syncthreads();
+      strip_update<2>(acc, B0, (bi == bj) ? B0 : B1, w4, 2 * grp);
+    }
     }
 #pragma unroll
     for (int nn = 0; nn < 2; nn++)
@@ -964,16 +972,18 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
 __device__ __attribute__((noinline)) void chol_tile_persist(double* __restrict__ S, int n, int ld, int k, int bi,
                                                             int bj, int* __restrict__ fail, double lm, double ep,
                                                             double* __restrict__ Ldiag, int* __restrict__ done,
-                                                            int* __restrict__ abortf, bool coh_first) {
-  chol_tile<true>((gbl_f64*)S, n, ld, k, bi, bj, fail, lm, ep, (gbl_f64*)Ldiag, done, abortf, coh_first);
+                                                            int* __restrict__ abortf, bool coh_first, int k_last) {
+  chol_tile<true>((gbl_f64*)S, n, ld, k, bi, bj, fail, lm, ep, (gbl_f64*)Ldiag, done, abortf, coh_first, k_last);
 }
 
 // OVERLAP mode (ready != nullptr; multi-GPU, SURVEY 8e / VERDICT r02 #6): the kernel is launched BEFORE the reduced
-// system is there.  The all-reduce of the packed system runs in row chunks on a side stream; each chunk is expanded
-// into S (damping applied there: pass lm = ep = 0 here) and then ready[block row] = epoch is published for its block
-// rows.  A tile (bi, bj) is first read by its owner at step -1 (column 0) or step 0 (all others): that read waits for
-// ready[bi] and goes past the L2 (sc1).  The diagonal chain reaches block row i after ~10.8 us x i while the rows up
-// to i are only (i / 24)^2 of the message, so after the first chunk the factorisation never waits for the collective.
+// system is there.  The all-reduce of the packed system (block-column major) runs in column chunks on a side stream;
+// each chunk is expanded into S (damping applied there: pass lm = ep = 0 here) and then ready[block column] = epoch
+// is published for its block columns.  A tile (bi, bj) is first read by its owner at its first step: that read waits
+// for ready[bj] and goes past the L2 (sc1); a plain trailing tile then replays all the updates it has missed in one
+// go (chol_tile, k_last).  Why columns: row i of L needs every earlier column, so a late block ROW costs a sweep as
+// long as the factorisation itself (measured: profiles/r03_overlap_emulation.txt), while a late block COLUMN j is not
+// needed before the chain gets there, ~10.8 us x j after the start.
 // The grid is capped below the CU count by the launcher, so the collective's and the unpack kernels always find CUs.
 #ifdef OV_DEBUG
 __device__ unsigned long long g_ov_dbg[64];
@@ -1018,14 +1028,14 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
 #endif
   if (ready != nullptr) {
     // ---- overlap mode: per-tile progress instead of the step-major walk below.  A workgroup owns up to a handful of
-    // tiles; stepping them in lockstep would park it at step 0 on a tile whose block row arrives with the LAST chunk
+    // tiles; stepping them in lockstep would park it at step 0 on a tile whose block column arrives with the LAST chunk
     // of the collective while its other tile sits on the chain.  Here every owned tile keeps its own next step; wave 0
     // scans them in ownership order (earlier block columns first), takes the first whose inputs are there -- the same
     // flags as below, polled once instead of waited for, plus ready[bi] at the tile's first step -- and spins
     // (bounded) only when none is.  Dependencies only point to earlier block columns, so skipping a waiting tile can
     // never starve the tile that is picked.
     constexpr int MAXT = 12;   // the launcher admits at most 10 tiles per workgroup
-    __shared__ int s_ti[MAXT], s_tj[MAXT], s_nx[MAXT], s_nt, s_pick;
+    __shared__ int s_ti[MAXT], s_tj[MAXT], s_nx[MAXT], s_nt, s_pick, s_klast;
     if (t == 0) {
       int nt = 0, cj = 0, cs = 0;
       for (int idx = wg; idx < total && nt < MAXT; idx += G) {
@@ -1043,7 +1053,7 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
     __syncthreads();
     while (true) {
       if (t < 64) {
-        int pick = -1, spins = 0;
+        int pick = -1, spins = 0, klast = -2;
         bool ok = true;
         const int nt = s_nt;
         while (true) {
@@ -1061,8 +1071,9 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
             if (t == 0 && flagged) p = &done[bi];
             else if (t == 1 && flagged && bj != bi) p = &done[bj];
             else if (t == 2 && k >= 0 && panel && bi != bj) { p = &dver[bj]; need = k; }
-            else if (t == 3 && first) p = &ready[bi], need = epoch;
-            bool sat = (p == nullptr) || cfp_load(p) >= need;
+            else if (t == 3 && first) p = &ready[bj], need = epoch;    // the tile's block column has been reduced
+            const int fv = (p == nullptr) ? 0x7fffffff : cfp_load(p);
+            bool sat = fv >= need;
             // Panel tiles and tiles of the next panel column take their two panel tiles strip by strip out of the
             // hand-over slots INSIDE the body, and wait there: enter only once the producers have started writing
             // (first strip of each slot no longer carries the preset tag) -- a producer in a block row that comes
@@ -1074,6 +1085,12 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
             }
             if (__all(sat)) {
               pick = i;
+              klast = k;
+              if (flagged) {  // plain trailing tile: how far are BOTH rows final?  done = 4 c + 3 for the last final column c
+                const int d0 = __shfl(fv, 0), d1 = (bj != bi) ? __shfl(fv, 1) : d0;
+                const int cok = (min(d0, d1) - 3) >> 2;
+                klast = max(k, min(cok, bj - 3));   // k = bj - 2 takes the strips from the slots, k = bj - 1 is the panel step
+              }
               break;
             }
           }
@@ -1087,6 +1104,7 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
         }
         if (t == 0) {
           s_pick = ok ? pick : -3;
+          s_klast = klast;
           if (!ok) {
             cfp_store(abortf, 1);
             atomicMax(fail, 2);
@@ -1099,17 +1117,18 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
       const int bi = __builtin_amdgcn_readfirstlane(s_ti[pick]), bj = __builtin_amdgcn_readfirstlane(s_tj[pick]);
       const int k = __builtin_amdgcn_readfirstlane(s_nx[pick]);
       const bool first = (k == ((bj == 0) ? -1 : 0));
-      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf, first);
+      const int klast = __builtin_amdgcn_readfirstlane(s_klast);
+      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf, first, klast);
 #ifdef OV_DEBUG
       if (t == 0 && bi == bj && bj == k + 1 && bj < 62) g_ov_dbg[bj] = wall_clock64();   // diagonal tile of column bj factored
 #endif
       if (bj != k + 1 && bi == bj) {  // publish the next version of a diagonal tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t == 0) cfp_store(&dver[bj], k + 1);
+        if (t == 0) cfp_store(&dver[bj], max(k, klast) + 1);
       }
       __syncthreads();
-      if (t == 0) s_nx[pick] = k + 1;
+      if (t == 0) s_nx[pick] = max(k, klast) + 1;
       __syncthreads();
     }
   }
@@ -1143,7 +1162,7 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
           if (t == 0 && flagged) p = &done[bi];
           else if (t == 1 && flagged && bj != bi) p = &done[bj];
           else if (t == 2 && k >= 0 && panel && bi != bj) { p = &dver[bj]; need = k; }
-          else if (t == 3 && first_touch) { p = &ready[bi]; need = epoch; }   // the tile's rows have been reduced
+          else if (t == 3 && first_touch) { p = &ready[bj]; need = epoch; }   // the tile's block column has been reduced
           bool sat = (p == nullptr);
           int spins = 0;
           // overlap mode waits for the collective (and, when ranks share a GPU, for another rank's grid): seconds, not ms
@@ -1173,7 +1192,7 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
       PSTAMP(12);
       __syncthreads();  // also: the previous tile's LDS reads are over
       if (s_abort) return;
-      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf, first_touch);
+      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf, first_touch, k);
       if (!panel && bi == bj) {  // publish the next version of a diagonal tile (panel tiles publish their strips)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's write-through stores are acknowledged
         __syncthreads();
@@ -1525,7 +1544,7 @@ static bool chol_cooperative() {
 
 // returns true when the single-launch kernel ran (the back-substitution may then use what it left in `ldiag`)
 // Overlap mode: the single-launch kernel only (returns false when it cannot be used: the caller then unpacks the
-// whole system and solves the ordinary way).  `ready` [block rows] / `epoch`: see the kernel.  The grid leaves
+// whole system and solves the ordinary way).  `ready` [block columns] / `epoch`: see the kernel.  The grid leaves
 // `reserve` CUs free for the collective and the unpack kernels (DROID_OVERLAP_RESERVE_CUS, default 32).
 bool launch_chol_factor_overlap(double* sys, int n, int ld, int* fail_flag, int* flags, double* ldiag,
                                 const int* ready, int epoch, hipStream_t s) {

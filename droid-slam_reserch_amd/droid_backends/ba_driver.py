@@ -149,7 +149,8 @@ class HipBackend:
         return self.dx
 
     # ---- overlap of the collective with the solve (opt-in: ShardedBA(overlap=True)) ----------------------------
-    OVERLAP_MAX_CHUNKS = 8
+    # chunks = collectives per iteration: each costs its own launch + synchronisation latency on the wire, so few
+    OVERLAP_MAX_CHUNKS = int(__import__("os").environ.get("DROID_BA_OVERLAP_CHUNKS", "4"))
 
     def overlap_plan(self):
         """[(first, last)] element ranges of `self.packed`, one per chunk (whole block rows of the system, in order)."""

@@ -147,8 +147,9 @@ int droid_ba_build(const float *poses, const float *disps, const float *intrinsi
                    int W, int M, int t0, int t1, int motion_only, void *workspace,
                    size_t workspace_bytes, void *stream);
 
-/* Multi-GPU variant of the build phase: the rank's contribution goes to a PACKED copy of the system -- row i
- * (0 <= i < 6P) holds columns 0..i in (i + 2) & ~1 doubles, the rhs row follows, rows are 16-byte aligned --
+/* Multi-GPU variant of the build phase: the rank's contribution goes to a PACKED copy of the system -- the lower
+ * triangle + rhs row by block columns of 64: block column J holds rows 64 J .. 6P (row 6P = rhs) as rows of w_J
+ * doubles (w_J = 64, the last one 6P - 64 J), block columns one after the other --
  * which droid_ba_packed_system() exposes as one contiguous fp64 tensor of *n_elements values: all-reduce (sum) it
  * over the ranks as it is (half the bytes of the pitched matrix, no gather / scatter of the triangle), then call
  * droid_ba_unpack_system (one launch: packed -> the pitched matrix the solver factors in place) and
@@ -164,14 +165,14 @@ int droid_ba_unpack_system(int E, int nbuf, int H, int W, int M, int t0, int t1,
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* Overlap of the collective with the solve (multi-GPU, opt-in).  The factorisation consumes
- * the system top-left to bottom-right and the packed system is row-major, so a PREFIX of it is all the leading block
- * rows need.  droid_ba_overlap_plan cuts the packed tensor into at most max_chunks contiguous element ranges
- * [packed_offsets[c], packed_offsets[c+1]) by block rows of 64 (2, 3, 4, 5, 5, ... block rows).  Per iteration:
+ * block columns left to right and the packed system is block-column major, so a PREFIX of it is all the leading
+ * block columns need.  droid_ba_overlap_plan cuts the packed tensor into at most max_chunks contiguous element
+ * ranges [packed_offsets[c], packed_offsets[c+1]) of 1, 1, 2, 3, 4, ... block columns.  Per iteration:
  *   main stream : droid_ba_build_packed ... droid_ba_solve_update_overlap(epoch)   -- launched BEFORE the reduction;
- *                 its factorisation waits, tile by tile, for the block rows it is about to read
+ *                 its factorisation waits, tile by tile, for the block columns it is about to read
  *   side stream : (after the build) for c = 0 .. nchunks-1: all-reduce chunk c of the packed tensor in place, then
- *                 droid_ba_unpack_chunk(c, lm, ep, epoch): rows -> pitched matrix with the damping applied, then the
- *                 block rows are published for `epoch`.
+ *                 droid_ba_unpack_chunk(c, lm, ep, epoch): columns -> pitched matrix with the damping applied, then
+ *                 the block columns are published for `epoch`.
  * epoch = 1, 2, ... within one droid_ba_prepare (which resets the published epochs).  The spinning grid leaves
  * DROID_OVERLAP_RESERVE_CUS (default 32) compute units free for the collective's kernels.  Returns DROID_E_ARG
  * when the single-launch solver cannot run this system (then: droid_ba_unpack_system + droid_ba_solve_update).
