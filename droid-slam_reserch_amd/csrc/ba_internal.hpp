@@ -52,6 +52,12 @@ __host__ __device__ inline size_t pk_index(int n, int gi, int gj) {   // gi >= 6
   const int J = gj / CHOL_NB;
   return pk_colbase(n, J) + (size_t)(gi - CHOL_NB * J) * (size_t)pk_width(n, J) + (size_t)(gj - CHOL_NB * J);
 }
+// the same in 32-bit arithmetic for the kernels' atomics (the packed tensor has < 2^31 elements up to n = 65 000)
+__host__ __device__ inline unsigned pk_index32(int n, int gi, int gj) {
+  const int J = gj >> 6, c0 = J << 6;
+  const int w = (n - c0) < CHOL_NB ? (n - c0) : CHOL_NB;
+  return (unsigned)(CHOL_NB * (J * (n + 1) - (CHOL_NB / 2) * J * (J - 1)) + (gi - c0) * w + (gj - c0));
+}
 
 enum { HDR_STATUS = 0, HDR_M = 1, HDR_CHOL_FAIL = 2, HDR_NENT = 3, HDR_NWORK = 4,
        HDR_NC1 = 5, HDR_NC2 = 6,  // slots served by the two SYRK variants (classes 1, 2)

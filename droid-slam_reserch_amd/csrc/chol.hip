@@ -556,11 +556,14 @@ __device__ __forceinline__ void chol_strip_out(gbl_f64* __restrict__ S, int ld, 
 // coh_first (overlap mode, see chol_factor_persistent_kernel): the tile's own values were written by ANOTHER kernel
 // while this one was already running (no kernel-boundary invalidate in between), so this read of them must go past
 // the XCD's L2 (sc1); later reads see the workgroup's own write-through stores as before.
-template <bool PERSIST>
+// OV = false compiles the two overlap-mode parameters out (the default path pays nothing for them).
+template <bool PERSIST, bool OV = false>
 __device__ __forceinline__ void chol_tile(gbl_f64* __restrict__ S, int n, int ld, int k, int bi, int bj,
                                           int* __restrict__ fail, double lm, double ep,
                                           gbl_f64* __restrict__ Ldiag, int* __restrict__ done,
-                                          int* __restrict__ abortf, bool coh_first = false, int k_last = -2) {
+                                          int* __restrict__ abortf, bool coh_first_arg = false, int k_last_arg = -2) {
+  const bool coh_first = OV && coh_first_arg;
+  const int k_last = OV ? k_last_arg : -2;
   lds_f64* const B0 = DROID_LDS(g_cholB0);      // L[bi,k]          (workgroup-local tiles, see their declaration)
   lds_f64* const B1 = DROID_LDS(g_cholB1);      // L[bj,k]
   lds_f64* const B2 = DROID_LDS(g_cholB2);      // the diagonal tile D -> L
@@ -969,11 +972,12 @@ __global__ __launch_bounds__(512) void chol_step_kernel(double* __restrict__ S, 
 
 // One tile of one step.  NOT inlined into the step loops: inlined, the loop-invariant lane offsets of the
 // whole body are hoisted in front of the loops and held (or spilled) across them.
+template <bool OV>
 __device__ __attribute__((noinline)) void chol_tile_persist(double* __restrict__ S, int n, int ld, int k, int bi,
                                                             int bj, int* __restrict__ fail, double lm, double ep,
                                                             double* __restrict__ Ldiag, int* __restrict__ done,
                                                             int* __restrict__ abortf, bool coh_first, int k_last) {
-  chol_tile<true>((gbl_f64*)S, n, ld, k, bi, bj, fail, lm, ep, (gbl_f64*)Ldiag, done, abortf, coh_first, k_last);
+  chol_tile<true, OV>((gbl_f64*)S, n, ld, k, bi, bj, fail, lm, ep, (gbl_f64*)Ldiag, done, abortf, coh_first, k_last);
 }
 
 // OVERLAP mode (ready != nullptr; multi-GPU, SURVEY 8e / VERDICT r02 #6): the kernel is launched BEFORE the reduced
@@ -991,11 +995,13 @@ extern "C" int droid_debug_overlap_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ov_dbg), sizeof(unsigned long long) * 64);
 }
 #endif
+template <bool OV>
 __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __restrict__ S, int n, int ld,
                                                                      int* __restrict__ fail, double lm, double ep,
                                                                      int* __restrict__ flags,
                                                                      double* __restrict__ Ldiag,
-                                                                     const int* __restrict__ ready, int epoch) {
+                                                                     const int* __restrict__ ready_arg, int epoch) {
+  const int* const ready = OV ? ready_arg : nullptr;   // (OV = false: every overlap branch below is compiled out)
   __shared__ int s_abort;
   const int nb = (n + NB - 1) / NB;       // block columns
   const int nrb = (n + 1 + NB - 1) / NB;  // block rows (row n = rhs)
@@ -1026,7 +1032,7 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
 #ifdef OV_DEBUG
   if (blockIdx.x == 0 && threadIdx.x == 0) g_ov_dbg[63] = wall_clock64();
 #endif
-  if (ready != nullptr) {
+  if (OV && ready != nullptr) {
     // ---- overlap mode: per-tile progress instead of the step-major walk below.  A workgroup owns up to a handful of
     // tiles; stepping them in lockstep would park it at step 0 on a tile whose block column arrives with the LAST chunk
     // of the collective while its other tile sits on the chain.  Here every owned tile keeps its own next step; wave 0
@@ -1118,7 +1124,7 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
       const int k = __builtin_amdgcn_readfirstlane(s_nx[pick]);
       const bool first = (k == ((bj == 0) ? -1 : 0));
       const int klast = __builtin_amdgcn_readfirstlane(s_klast);
-      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf, first, klast);
+      chol_tile_persist<true>(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf, first, klast);
 #ifdef OV_DEBUG
       if (t == 0 && bi == bj && bj == k + 1 && bj < 62) g_ov_dbg[bj] = wall_clock64();   // diagonal tile of column bj factored
 #endif
@@ -1192,7 +1198,7 @@ __global__ __launch_bounds__(512) void chol_factor_persistent_kernel(double* __r
       PSTAMP(12);
       __syncthreads();  // also: the previous tile's LDS reads are over
       if (s_abort) return;
-      chol_tile_persist(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf, first_touch, k);
+      chol_tile_persist<false>(S, n, ld, k, bi, bj, fail, lm, ep, Ldiag, done, abortf, false, k);
       if (!panel && bi == bj) {  // publish the next version of a diagonal tile (panel tiles publish their strips)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's write-through stores are acknowledged
         __syncthreads();
@@ -1468,7 +1474,7 @@ static int chol_resident_workgroups() {
     int dev = 0, occ = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, chol_factor_persistent_kernel, 512, 0) != hipSuccess)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, chol_factor_persistent_kernel<false>, 512, 0) != hipSuccess)
       cached = 0;
     else
       cached = occ * prop.multiProcessorCount;
@@ -1558,7 +1564,7 @@ bool launch_chol_factor_overlap(double* sys, int n, int ld, int* fail_flag, int*
   const int grid = total < cap ? total : cap;
   auto lock = persist_enter(s);
   const double zero = 0.0;
-  hipLaunchKernelGGL(chol_factor_persistent_kernel, dim3(grid), dim3(512), 0, s, sys, n, ld, fail_flag, zero, zero,
+  hipLaunchKernelGGL(chol_factor_persistent_kernel<true>, dim3(grid), dim3(512), 0, s, sys, n, ld, fail_flag, zero, zero,
                      flags, ldiag, ready, epoch);
   return true;
 }
@@ -1580,11 +1586,11 @@ bool launch_chol_factor(double* sys, int n, int ld, double lm, double ep, int* f
       const int* no_ready = nullptr;
       int no_epoch = 0;
       void* args[] = {&sys, &n, &ld, &fail_flag, &lm, &ep, &flags, &ldiag, &no_ready, &no_epoch};
-      if (hipLaunchCooperativeKernel((const void*)chol_factor_persistent_kernel, dim3(grid), dim3(512), args, 0, s) == hipSuccess)
+      if (hipLaunchCooperativeKernel((const void*)chol_factor_persistent_kernel<false>, dim3(grid), dim3(512), args, 0, s) == hipSuccess)
         return true;
       (void)hipGetLastError();  // refused (grid cannot be resident now): per-step kernels below
     } else {
-      hipLaunchKernelGGL(chol_factor_persistent_kernel, dim3(grid), dim3(512), 0, s, sys, n, ld, fail_flag, lm,
+      hipLaunchKernelGGL(chol_factor_persistent_kernel<false>, dim3(grid), dim3(512), 0, s, sys, n, ld, fail_flag, lm,
                          ep, flags, ldiag, (const int*)nullptr, 0);
       return true;
     }
