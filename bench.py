@@ -549,7 +549,7 @@ def main():
         HW, E_l, M_l, Nk, P = info["HW"], info["E_local"], info["M_local"], info["N"], info["P"]
         n = 6 * P
         pmc, pmc_src = {}, None
-        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 pmc_src = "profiles/" + name
@@ -558,7 +558,7 @@ def main():
                 continue
 
         def traffic(kernel):
-            k = pmc.get(kernel)
+            k = pmc.get(kernel) or pmc.get(kernel.replace("<false>", ""))   # (r01 / r02 summaries: not yet a template)
             if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
                 return None
             return (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
@@ -582,7 +582,7 @@ def main():
         nk = deg + 1
         schur_flops = float(np.sum((6 * nk) * (6 * nk + 1) * HW + 6 * nk * HW)) * (E_l / max(1, len(prob.ii)))
         kernels = [
-            flop("droid::chol_factor_persistent_kernel", "factor", n ** 3 / 3.0, FP64_VEC_PEAK_TFLOPS,
+            flop("droid::chol_factor_persistent_kernel<false>", "factor", n ** 3 / 3.0, FP64_VEC_PEAK_TFLOPS,
                  "fp64 Cholesky of the (6P)^2 reduced camera system in one launch, n^3/3 flops over ceil(n/64) "
                  "dependent block columns: a pivot-latency chain, priced against the fp64 vector/MFMA peak"),
             hbm("droid::ba_lin_kernel<true, false, false>", "linearize", 16.0 * E_l * HW + 16.0 * M_l * HW + 56.0 * Nk,
