@@ -84,7 +84,7 @@ struct BaView {
   int* wk_ptr;             // [nbuf+1] scratch (slot sizes while sorting)
   int* order;              // [nbuf+1] slots sorted by descending edge count: big slots are dispatched first
   int* xtmp;               // [3(E+1)] prep scratch: unsorted segment fill, window flag and slot of every sorted position
-  int* cls_list;           // [2][nbuf+2] the slots of SYRK class 1 / class 2, ascending (ba_syrk_kernel)
+  int* cls_list;           // [2][nbuf+2] the slots of SYRK class 1 / class 2, ascending (ba_syrk3_kernel)
   int* gt_ptr;             // [nbuf+2] first partial-sum tile of a slot served by ba_schur2_kernel (exclusive scan)
   double* Gpart;           // [tiles][s2_split][256] fp64 partial sums of those slots' Gram tiles, one per pixel range
   int s2_split;            // pixel ranges per slot of ba_schur2_kernel
@@ -92,8 +92,10 @@ struct BaView {
   float* Q;                // [M][HW] 1/C
   float* w;                // [M][HW]
   float* Erows;            // unused (nullptr): sparse slots recompute their E rows where they are consumed
-  float* Ebuf;             // dense graphs only (`wide`): unscaled E rows [6*(M+E)][HW], row 6*(entry)+n, written by
-                           // the linearisation and consumed by the SYRK-only Schur kernel
+  float* Ebuf;             // dense graphs only (`wide`): unscaled E rows, 6*(M+E)*HW floats, per slot tiled by 32-pixel stage
+                           // (ba_kernels.hip::ebuf_index), written by the linearisation and consumed by the SYRK-only Schur kernels
+  float* sy_part[2];       // dense graphs: fp32 tiles of S per (slot of SYRK class 1 / 2, pixel range), summed by ba_syrk_fold_kernel
+  int sy_ns[2];            // pixel splits (grid y) of the two SYRK launches
   int wide;                // host decision: mean out-degree >= 12 (dense global BA, edge-sharded ranks)
   int zsplit;              // linearisation: workgroups per (slot, pixel chunk), each takes a range of the slot's edges
   float* zpart;            // zsplit > 1: [zsplit][M][8][HW] partial C, w and self-row sums of those workgroups
@@ -147,6 +149,20 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.wide = (M > 0 && (long)E >= 12l * M && (v.HW % 32) == 0) ? 1 : 0;
   v.Ebuf = nullptr;   // ... except for dense graphs, where the recomputation would be repeated per output share
   if (v.wide) v.Ebuf = static_cast<float*>(take(sizeof(float) * (6 * ((size_t)M + E) * v.HW + 64)));
+  v.sy_part[0] = v.sy_part[1] = nullptr;
+  v.sy_ns[0] = v.sy_ns[1] = 0;
+  if (v.wide) {
+    // pixel splits of the SYRK launches: enough (slot, range) workgroups to fill 256 CUs (class 1: one 12-wave workgroup per
+    // CU; class 2: four shares per pair); a split costs a set of partial tiles, no atomics.  A launch has M * ns pairs at most:
+    // 136 (class 1: <= 256 rows) or 528 (class 2: <= 512 rows) tiles of 1 KB each
+    const int stages = v.HW / 32;
+    int nsw = (512 + M - 1) / M, nsb = (256 + 4 * M - 1) / (4 * M);
+    nsw = nsw < 2 ? 2 : (nsw > stages ? stages : nsw);
+    nsb = nsb < 2 ? 2 : (nsb > stages ? stages : nsb);
+    v.sy_ns[0] = nsw; v.sy_ns[1] = nsb;
+    v.sy_part[0] = static_cast<float*>(take(sizeof(float) * ((size_t)M * nsw * 136 * 256 + 64)));
+    v.sy_part[1] = static_cast<float*>(take(sizeof(float) * ((size_t)M * nsb * 528 * 256 + 64)));
+  }
   // few depth slots (edge-sharded ranks, small windows): split every slot's edges over several
   // workgroups so that the linearisation still fills the chip
   v.zsplit = 1;

@@ -14,6 +14,7 @@
 //   * S = E C^-1 E^T is a batched SYRK on v_mfma_f32_16x16x4_f32, one wave per 16x16 tile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ba_internal.hpp"
 #include "se3.hpp"
@@ -140,7 +141,7 @@ typedef SlotMetaT<float> SlotMeta;
 constexpr int SF_TP = 64;             // pixels per LDS tile; 4 threads per pixel split the edges
 constexpr int SF_RB = 96;             // rows per block (16 entries)
 // Dense slots (more than 16 entries) are served by the SYRK-only kernel further down.
-constexpr int SW_MID = 272;   // rows (incl. the w row) served by the two-workgroups-per-CU variant (45 entries)
+constexpr int SW_MID = 256;   // rows (incl. the w row) served by the two-workgroups-per-CU variant (42 entries; two staging rounds of 128 rows)
 constexpr int SW_BIG = 512;   // rows served by the one-per-CU variant (85 entries)
 constexpr int SY_MAXSPLIT = 16;  // pixel ranges per slot of the SYRK kernels (each adds one fp64 atomic per output entry)
 
@@ -153,6 +154,13 @@ __device__ __forceinline__ int schur_class(int rows, int nedges, int wide) {
   if (nedges <= S2_MAXE) return 0;
   if (!wide || nedges > SLOT_MAXE || rows > SW_BIG) return 3;
   return rows <= SW_MID ? 1 : 2;
+}
+// v.Ebuf (dense graphs): the E rows of a slot, TILED by 32-pixel stage -- float (stage s, row, pixel o) of the slot whose
+// first entry is e0 and which has `rows` = 6 nent E rows sits at 6 e0 HW + (s rows + row) 32 + o.  One stage of all rows is
+// one contiguous block (rows x 128 B): the SYRK kernels stream it; row-major rows (12 KB apart at 48x64) made every
+// 128-byte request open another DRAM page and held the stream at 1.6 TB/s.
+__device__ __forceinline__ size_t ebuf_index(int e0, int rows, int HW, int row, int k) {
+  return (size_t)6 * e0 * HW + ((size_t)(k >> 5) * rows + row) * 32 + (k & 31);
 }
 // 256-double units a (class-0 slot, pixel range) leaves in v.Gpart: the 16x16 Gram tiles of its 6 nedges E rows
 // (lower triangle of row tiles) + one unit for the 6 nedges sums of E Q w
@@ -462,10 +470,11 @@ __global__ __launch_bounds__(LIN_THREADS, 3) void ba_lin_kernel(
 
   // E-row emission for this slot?
   bool emit = false, has_self = false;
-  int e0 = 0;
+  int e0 = 0, erows = 0;
   if (DEPTH && EROWS) {
     e0 = v.ent_ptr[m];
     const int nent = v.ent_ptr[m + 1] - e0;
+    erows = 6 * nent;
     const int cls = schur_class(6 * nent + 1, xe - xb, 1);
     emit = (cls == 1 || cls == 2);
     has_self = nent > 0 && (v.ent_row[e0] < v.M);
@@ -583,7 +592,7 @@ __global__ __launch_bounds__(LIN_THREADS, 3) void ba_lin_kernel(
           const int a = sm.ent[xl];
           if (a >= 0) {
 #pragma unroll
-            for (int n = 0; n < 6; n++) v.Ebuf[(size_t)(6 * (e0 + a) + n) * HW + k] = eij[n];
+            for (int n = 0; n < 6; n++) v.Ebuf[ebuf_index(e0, erows, HW, 6 * a + n, k)] = eij[n];
           }
           if (has_self) {
             float eii[6];
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(LIN_THREADS, 3) void ba_lin_kernel(
         v.w[o] = w;
         if (EROWS && emit && has_self) {
 #pragma unroll
-          for (int n = 0; n < 6; n++) v.Ebuf[(size_t)(6 * e0 + n) * HW + k] = selfacc[p][n];
+          for (int n = 0; n < 6; n++) v.Ebuf[ebuf_index(e0, erows, HW, n, k)] = selfacc[p][n];
         }
       }
     }
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(256) void ba_lin_finish_kernel(BaView v, const floa
     const int cls = schur_class(6 * nent + 1, v.seg_ptr[m + 1] - v.seg_ptr[m], 1);
     if ((cls == 1 || cls == 2) && nent > 0 && v.ent_row[e0] < v.M) {
 #pragma unroll
-      for (int n = 0; n < 6; n++) v.Ebuf[(size_t)(6 * e0 + n) * HW + k] = s[2 + n];
+      for (int n = 0; n < 6; n++) v.Ebuf[ebuf_index(e0, 6 * nent, HW, n, k)] = s[2 + n];
     }
   }
 }
@@ -1479,33 +1488,66 @@ __device__ __forceinline__ void tri_coords(int ti, int& ta, int& tb) {
 
 // ------------------------------------------------------------------------------------------
 // Dense slots, SYRK only.  With 17..85 entries per slot the accumulators of S = B Q B^T no longer
-// fit one CU, so several workgroups share the output tiles of a (slot, pixel range) and each
-// needs ALL rows of the slot: recomputing the E rows per share repeats the
-// whole staging arithmetic 2-4 times and alternates VALU and MFMA phases (an earlier kernel of this
-// file did exactly that: 0.50 ms for the Schur complement of an 8-way edge shard).  For such graphs the
-// linearisation writes the unscaled E rows once (v.Ebuf) and this kernel only streams them:
-// 32-pixel stages of all rows (+ the w row and the Q row) arrive by LDS-DMA (global_load_lds_dwordx4
-// from inline asm, two buffers, the DMA of stage s+1 in flight while stage s is multiplied), the
-// LDS image is lane-linear (128 B per row) with the XOR swizzle applied on the source side
-// (16-byte slot c of row r holds chunk c ^ (r & 7): 8 consecutive rows cover all banks), K runs
-// in the permuted order (k-step (s,e) of lane group g = pixel 16s+4g+e) and the A operand is
-// scaled by Q on the fly: S_ij = sum_k (B_ik Q_k) B_jk; row R = w gives the reduced rhs E Q w.
+// fit one wave's share of a small workgroup, and every workgroup that shares the output tiles of a (slot, pixel range)
+// needs ALL rows of the slot: recomputing the E rows per share repeats the whole staging arithmetic and alternates VALU and
+// MFMA phases (an earlier kernel of this file did exactly that: 0.50 ms for the Schur complement of an 8-way edge shard).
+// For such graphs the linearisation writes the unscaled E rows once (v.Ebuf, tiled by 32-pixel stage: ebuf_index) and the
+// kernel below only streams them.  Output in 32x32 super-tiles (2x2 MFMA tiles): one A fragment serves two B fragments.
+// Rounds 1-2 ran this on v_mfma_f32_16x16x4_f32 with LDS-DMA staging and folded with fp64 atomics (528 us for the 256
+// slots of BASELINE configs[3], of which the 12 M atomics were ~135 us: profiles/r03_dense_syrk_ab.txt).
 // ------------------------------------------------------------------------------------------
 constexpr int SY_TPX = 32;  // pixels per stage
+constexpr int SY_T1 = 16 * 17 / 2, SY_T2 = 32 * 33 / 2;  // 16x16 tiles of a class-1 / class-2 slot's lower triangle (ba_internal.hpp sizes v.sy_part with the same numbers)
 
-template <int ROWS, int MINWG, int CLS, int NSHARE>
-__global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
-  // Output is processed in 32x32 super-tiles (2x2 MFMA tiles): one A fragment serves two B fragments and
-  // vice versa, which halves the LDS operand traffic (with one 16x16 tile per step the LDS reads --
-  // 512 B per MFMA -- cost as much time as the MFMAs themselves).
-  constexpr int NW = 8, NST = (ROWS / 16 + 1) / 2;
+// ------------------------------------------------------------------------------------------
+// S = B~ B~^T on the bf16 matrix pipe at fp32 accuracy (round 3).  Every fp32 operand B~ = E sqrt(Q) is split into three
+// bf16 terms, x = b0 + b1 + b2 (round to nearest: exact to 2^-27 |x|), and a 32-pixel k step becomes the six products of
+// order <= 2 on v_mfma_f32_16x16x32_bf16 -- b0b0, b0b1, b1b0, b0b2, b1b1, b2b0; a bf16 x bf16 product is exact in fp32 and
+// the 32 products of a step are summed inside the instruction, so the chain has FEWER fp32 roundings than the
+// v_mfma_f32_16x16x4_f32 chain it replaces (tools/micro/mfma_acc_bf16.hip: unbiased, 0.7x its rms error); dropped terms
+// 2^-26.  6 x 16 cycles instead of 8 x 32 per tile and step.
+// Staging: no fp32 image in LDS.  Thread t owns the 16-byte k groups (row, g) = (t >> 2, t & 3) (+ 128 rows per round): it
+// loads its 8 pixels of the E row straight into registers (the loads of stage s+1 are in flight while stage s is multiplied),
+// scales them by sqrt(Q), splits, and writes three 16-byte chunks; chunk (plane p, k group g, row) sits at
+// ((4p + g) NR + row) x 16 B with NR = 4 mod 16: the operand read of a tile (16 consecutive rows, one g per 16 lanes) and
+// the staging write (4 consecutive rows x 4 k groups per 16 lanes) are both conflict-free.  Row R = w sqrt(Q) gives E Q w.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  const bf16x2 h = __builtin_convertvector((f32x2){a, b}, bf16x2);
+  return __builtin_bit_cast(unsigned, h);
+}
+
+// x[0..7] -> three planes of 8 bf16 (k order = element order)
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], u32x4& p0, u32x4& p1, u32x4& p2) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const float xa = x[2 * e], xb = x[2 * e + 1];
+    const unsigned h0 = cvt_pk_bf16(xa, xb);
+    const float ra = xa - __uint_as_float(h0 << 16), rb = xb - __uint_as_float(h0 & 0xffff0000u);
+    const unsigned h1 = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(h1 << 16), sb = rb - __uint_as_float(h1 & 0xffff0000u);
+    p0[e] = h0;
+    p1[e] = h1;
+    p2[e] = cvt_pk_bf16(sa, sb);
+  }
+}
+
+// NWV waves per workgroup; NSHARE workgroups share the super-tiles of a (slot, pixel range) -- each of them stages ALL rows,
+// so the dense class runs ONE 16-wave workgroup per CU (every row converted once) with two plane buffers (one barrier per
+// step, the conversion of step s+1 beside the products of step s) and the loads two steps ahead.
+template <int ROWS, int NWV, int CLS, int NSHARE, bool DBUF>
+__global__ __launch_bounds__(64 * NWV) void ba_syrk3_kernel(BaView v) {
+  constexpr int NW = NWV, NTH = 64 * NWV, NST = (ROWS / 16 + 1) / 2;
   constexpr int MAXS = ((NST * (NST + 1) / 2 + NSHARE - 1) / NSHARE + NW - 1) / NW;  // super-tiles per wave
-  constexpr int BUF_FLOATS = (ROWS + 8) * SY_TPX;       // + the Q row, rounded up to a DMA group of 8 rows
-  constexpr int MAXSLOT = ((ROWS + 8) / 8 + NW - 1) / NW;  // DMA instructions per wave and stage
-  __shared__ __attribute__((aligned(16))) float EB[2][BUF_FLOATS];
-  // workgroups (x, y) are dealt over the slots of this class (prep's compact list): w -> (slot w % count,
-  // pixel range w / count).  A class with few slots (two hub frames of an otherwise class-1 graph) gets up to
-  // SY_MAXSPLIT pixel ranges per slot instead of the launch-wide split chosen for `M` slots.
+  constexpr int NR = ((ROWS + 15) & ~15) + 16 + 4;  // rows of a (plane, k group) panel (+ one tile row of slack), = 4 mod 16
+  constexpr int MAXT = (4 * ROWS + NTH - 1) / NTH;  // k groups a thread stages per step
+  constexpr int PD = DBUF ? 2 : 1;                  // steps the global loads run ahead
+  __shared__ u32x4 PL[(DBUF ? 2 : 1) * 12 * NR];
   const int count = min(v.hdr[HDR_NC1 + CLS - 1], v.M);
   if (count <= 0) return;
   const int HW = v.HW;
@@ -1518,20 +1560,14 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int e0 = v.ent_ptr[m], nent = v.ent_ptr[m + 1] - e0;
-  const int R = 6 * nent;  // E rows; row R is the w row, row R+1 the Q row
-  // pose index of every entry, for the fold (6 rows per entry; dependent global loads per folded element otherwise)
-  __shared__ int s_pose[(ROWS + 5) / 6 + 1];
-  for (int i = tid; i < nent; i += (int)blockDim.x) s_pose[i] = v.ent_pose[e0 + i];
+  const int R = 6 * nent;  // E rows; row R is the w row
   const int spw = (stages_total + nrange - 1) / nrange;
   const int st_beg = range * spw, st_end = min(stages_total, st_beg + spw);
   if (st_beg >= st_end) return;
   const int ntr = (R + 1 + 15) / 16;              // 16-row tiles
   const int nst = (ntr + 1) / 2;                  // 32-row super-tile rows
   const int nsup_all = nst * (nst + 1) / 2;       // lower triangle of super-tiles
-  // Super-tiles differ in cost: a diagonal one has no use for its strict upper tile (3 of 4 tiles), the last block row of
-  // an odd tile count has one tile row only (2 of 4; 1 in the corner).  They are sorted by cost and dealt out in that
-  // order -- position p to share p % NSHARE, there to the waves back and forth (0..7, 7..0, ..) -- so that shares, the
-  // four SIMDs and the waves all carry nearly the same number of MFMAs (13 row tiles: 91 useful tiles of 112).
+  // super-tiles sorted by cost and dealt over shares, SIMDs and waves (see ba_syrk_kernel)
   __shared__ unsigned char s_cost[NST * (NST + 1) / 2];
   __shared__ short s_sorted[NST * (NST + 1) / 2];
   for (int i = tid; i < nsup_all; i += (int)blockDim.x) {
@@ -1553,38 +1589,68 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
   __syncthreads();
   const int nsup = (nsup_all - (int)blockIdx.z + NSHARE - 1) / NSHARE;  // super-tiles of this workgroup
   if (nsup <= 0) return;
-  // this wave's u-th super-tile: dealt position 8u + wave (u even) or 8u + 7 - wave (u odd)
   int mysup[MAXS];
-  int nmine = 0;
 #pragma unroll
   for (int u = 0; u < MAXS; u++) {
     const int kpos = NW * u + ((u & 1) ? NW - 1 - wave : wave);
     mysup[u] = __builtin_amdgcn_readfirstlane(kpos < nsup ? (int)s_sorted[kpos] : -1);
-    nmine += (mysup[u] >= 0) ? 1 : 0;
   }
 
-  // staging plan: DMA instruction k covers rows 8k..8k+7 (lane >> 3), 16-byte slot lane & 7 of each
-  const int nrows = R + 2;
-  const int ngrp = (nrows + 7) >> 3;
-  const float* src[MAXSLOT];
+  // staging plan.  No branch around a global load anywhere below (the waitcnt pass counts loads only through straight
+  // code; a predicated load made it drain everything at the loop head): every lane loads in every round, from a
+  // clamped row; a round whose rows lie past the slot is skipped per WAVE around the conversion only, lanes past the
+  // slot inside a needed round write their chunks to the slack row NR - 1.
+  const int nrows = R + 1;
+  const int sg = tid & 3;
+  const float* src[MAXT];
+  int sstep[MAXT];
+  int dst[MAXT];      // chunk index of plane 0
+  bool needed[MAXT];  // wave-uniform
 #pragma unroll
-  for (int it = 0; it < MAXSLOT; it++) {
-    const int row = min(8 * (wave + NW * it) + (lane >> 3), nrows - 1);  // pad lanes re-read the Q row
-    const float* rp = row < R ? v.Ebuf + (size_t)(6 * e0 + row) * HW
-                              : (row == R ? v.w + (size_t)m * HW : v.Q + (size_t)m * HW);
-    src[it] = rp + 4 * ((lane & 7) ^ (row & 7));
+  for (int it = 0; it < MAXT; it++) {
+    const int row = (tid >> 2) + (NTH / 4) * it;
+    const int rr = min(row, nrows - 1);
+    src[it] = (rr < R ? v.Ebuf + ebuf_index(e0, R, HW, rr, 0) : v.w + (size_t)m * HW) + 8 * sg;
+    sstep[it] = rr < R ? 32 * R : 32;  // the E rows are tiled by stage: one stage of all rows is one contiguous block
+    dst[it] = sg * NR + (row < nrows ? row : NR - 1);
+    needed[it] = (NTH / 4) * it + 16 * wave < nrows;
   }
-  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) float*)&EB[0][0]);
-  auto issue_stage = [&](int st, int buf) {
+  const float* qsrc = v.Q + (size_t)m * HW + 8 * sg;
+  f32x4 pf[PD][MAXT][2], pq[2];  // (the Q row is hot in the caches: its loads run one step ahead only)
+  auto load_q = [&](int st) {
+    const size_t o = (size_t)min(st, st_end - 1) * SY_TPX;
+    pq[0] = *reinterpret_cast<const f32x4*>(qsrc + o);
+    pq[1] = *reinterpret_cast<const f32x4*>(qsrc + o + 4);
+  };
+  auto load_stage = [&](int st, int k) {  // past the end: the last stage again (never consumed)
+    const size_t sc = (size_t)min(st, st_end - 1);
 #pragma unroll
-    for (int it = 0; it < MAXSLOT; it++) {
-      const int k = wave + NW * it;
-      if (k < ngrp) {  // wave-uniform
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 4u * (unsigned)(buf * BUF_FLOATS + k * 8 * SY_TPX));
-        const float* gsrc = src[it] + (size_t)st * SY_TPX;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    for (int it = 0; it < MAXT; it++) {
+      const float* g = src[it] + sc * sstep[it];
+      pf[k][it][0] = *reinterpret_cast<const f32x4*>(g);
+      pf[k][it][1] = *reinterpret_cast<const f32x4*>(g + 4);
+    }
+  };
+  auto store_stage = [&](int k, int buf) {
+    float sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) sq[e] = __builtin_amdgcn_sqrtf(pq[e >> 2][e & 3]);
+#pragma unroll
+    for (int it = 0; it < MAXT; it++) {
+      if (needed[it]) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[e] = pf[k][it][e >> 2][e & 3] * sq[e];
+        u32x4 p0, p1, p2;
+#ifdef SY3_NO_CONV
+        p0 = __builtin_bit_cast(u32x4, pf[k][it][0]); p1 = __builtin_bit_cast(u32x4, pf[k][it][1]); p2 = p0;
+#else
+        split3_bf16(x, p0, p1, p2);
+#endif
+        u32x4* P = PL + buf * 12 * NR + dst[it];
+        P[0] = p0;
+        P[4 * NR] = p1;
+        P[8 * NR] = p2;
       }
     }
   };
@@ -1595,80 +1661,131 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
   for (int u = 0; u < MAXS; u++)
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[u][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // LDS float offsets of this lane's operand rows per super-tile (constant over the stages); row + 16
-  // keeps (row & 7), so the second tile row of a super-tile sits exactly 16 rows further.  A second
-  // row block past the slot's tiles is folded onto the first (its results are never read).
+  // plane-0 chunk of this lane's operand row of the first tile row / column of a super-tile: lane part + a scalar
+  // (kept apart: six lane registers less across the stage loop)
+  const int offl = g * NR + r;
   int offa[MAXS], offb[MAXS];
-  bool upper[MAXS], second[MAXS];  // wave-uniform: the (a0, b1) tile is used / the second tile row exists
+  bool upper[MAXS], second[MAXS];
 #pragma unroll
   for (int u = 0; u < MAXS; u++) {
     int sa, sb;
     tri_coords(max(mysup[u], 0), sa, sb);
-    const int ra = 32 * sa + r, rb = 32 * sb + r;
-    offa[u] = ra * SY_TPX + 4 * (g ^ (ra & 7));
-    offb[u] = rb * SY_TPX + 4 * (g ^ (rb & 7));
-    upper[u] = (sa != sb);                 // (an off-diagonal super-tile never sits in the last block column)
+    offa[u] = __builtin_amdgcn_readfirstlane(32 * sa);
+    offb[u] = __builtin_amdgcn_readfirstlane(32 * sb);
+    upper[u] = (sa != sb);
     second[u] = (2 * sa + 1 < ntr);
   }
-  const int qrow = R + 1;
-  const int offq = qrow * SY_TPX + 4 * (g ^ (qrow & 7));
-  issue_stage(st_beg, 0);
-  for (int st = st_beg; st < st_end; st++) {
-    const int buf = (st - st_beg) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage st has landed
-    __builtin_amdgcn_s_barrier();                     // everybody's has; stage st-1 is consumed
-    if (st + 1 < st_end) issue_stage(st + 1, buf ^ 1);
-    const float* Eb = EB[buf];
-    // chunk index of k-half h is 4h + g: slot (4h + g) ^ (row & 7) = (g ^ (row & 7)) ^ 4h, i.e. the two
-    // halves of a row sit 16 floats apart: XOR 16 on the float offset
-    f32x4 qv[2];
-    qv[0] = *reinterpret_cast<const f32x4*>(&Eb[offq]);
-    qv[1] = *reinterpret_cast<const f32x4*>(&Eb[offq ^ 16]);
+  // D = sum over the six products of order <= 2 of two split operands, two tiles interleaved.  The products of a step
+  // start from zero and join the running total on the VALU: the instruction adds its 32 products and C with
+  // truncation-like alignment when C is large (tools/micro/mfma_acc_bf16.hip, "wide range": bias -5e-8 .. -2e-7 with a
+  // running accumulator, none with a fresh one).
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto mm2 = [&](const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4& t, const bf16x8 (&a2)[3], const bf16x8 (&b2)[3], f32x4& t2) {
+    f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], zero4, 0, 0, 0);
+    f32x4 c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], b2[2], zero4, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[2], b2[0], c2, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], b2[1], c2, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], b2[1], c2, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], b2[0], c2, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], b2[0], c2, 0, 0, 0);
+    t += c;
+    t2 += c2;
+  };
+  auto mm1 = [&](const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4& t) {
+    f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], zero4, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+    t += c;
+  };
+  auto multiply = [&](int buf) {
+#ifdef SY3_NO_MM
+    return;
+#endif
+    const u32x4* P = PL + buf * 12 * NR;
+#ifdef SY3_NO_LDSREAD
+    auto frag = [&](int chunk) { u32x4 t = {(unsigned)chunk, 1u, 2u, 3u}; asm volatile("" : "+v"(t)); return __builtin_bit_cast(bf16x8, t); };
+#else
+    auto frag = [&](int chunk) { return __builtin_bit_cast(bf16x8, P[chunk]); };
+#endif
 #pragma unroll
     for (int u = 0; u < MAXS; u++) {
-      if (mysup[u] >= 0) {  // wave-uniform; up to four independent accumulation chains per super-tile
+      if (mysup[u] >= 0) {  // wave-uniform
+        bf16x8 a0[3], a1[3], b0[3], b1[3];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          f32x4 a0 = *reinterpret_cast<const f32x4*>(&Eb[offa[u] ^ (16 * h)]);
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Eb[offb[u] ^ (16 * h)]);
-          a0 = a0 * qv[h];
-          if (second[u]) {
-            f32x4 a1 = *reinterpret_cast<const f32x4*>(&Eb[(offa[u] + 16 * SY_TPX) ^ (16 * h)]);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Eb[(offb[u] + 16 * SY_TPX) ^ (16 * h)]);
-            a1 = a1 * qv[h];
-            asm volatile("" : "+v"(a0), "+v"(a1));  // all products first (the compiler recycles one register otherwise)
-            if (upper[u]) {
+        for (int p = 0; p < 3; p++) {
+          a0[p] = frag(offl + offa[u] + 4 * p * NR);
+          b0[p] = frag(offl + offb[u] + 4 * p * NR);
+        }
+        if (second[u]) {
 #pragma unroll
-              for (int e = 0; e < 4; e++) {
-                acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc[u][0], 0, 0, 0);
-                acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b1[e], acc[u][1], 0, 0, 0);
-                acc[u][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b0[e], acc[u][2], 0, 0, 0);
-                acc[u][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc[u][3], 0, 0, 0);
-              }
-            } else {
+          for (int p = 0; p < 3; p++) a1[p] = frag(offl + offa[u] + 16 + 4 * p * NR);
+          mm2(a0, b0, acc[u][0], a1, b0, acc[u][2]);
 #pragma unroll
-              for (int e = 0; e < 4; e++) {
-                acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc[u][0], 0, 0, 0);
-                acc[u][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b0[e], acc[u][2], 0, 0, 0);
-                acc[u][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc[u][3], 0, 0, 0);
-              }
-            }
-          } else if (upper[u]) {  // last block row of an odd tile count: one tile row against two tile columns
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Eb[(offb[u] + 16 * SY_TPX) ^ (16 * h)]);
+          for (int p = 0; p < 3; p++) b1[p] = frag(offl + offb[u] + 16 + 4 * p * NR);
+          if (upper[u]) mm2(a0, b1, acc[u][1], a1, b1, acc[u][3]);
+          else mm1(a1, b1, acc[u][3]);
+        } else if (upper[u]) {  // last block row of an odd tile count: one tile row against two tile columns
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-              acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc[u][0], 0, 0, 0);
-              acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b1[e], acc[u][1], 0, 0, 0);
-            }
-          } else {  // its corner
-#pragma unroll
-            for (int e = 0; e < 4; e++) acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], acc[u][0], 0, 0, 0);
-          }
+          for (int p = 0; p < 3; p++) b1[p] = frag(offl + offb[u] + 16 + 4 * p * NR);
+          mm2(a0, b0, acc[u][0], a0, b1, acc[u][1]);
+        } else {  // its corner
+          mm1(a0, b0, acc[u][0]);
         }
       }
     }
+  };
+
+  // __syncthreads() would also drain the global loads in flight (s_waitcnt vmcnt(0)): the LDS traffic is all that has to
+  // be ordered here, the prefetched registers are waited for where they are used
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  if constexpr (!DBUF) {
+    load_q(st_beg);
+    load_stage(st_beg, 0);
+    for (int st = st_beg; st < st_end; st++) {
+      lds_barrier();  // the planes of step st-1 are consumed
+      store_stage(0, 0);
+      lds_barrier();  // the planes of step st are complete
+      load_q(st + 1);
+      load_stage(st + 1, 0);
+      multiply(0);
+    }
+  } else {
+    // steps in pairs so that the register sets and the plane buffers have compile-time indices; in step s the planes of
+    // s+1 are written (their readers finished before the last barrier) and the loads of s+3 issued
+    load_q(st_beg);
+    load_stage(st_beg, 0);
+    load_stage(st_beg + 1, 1);
+    store_stage(0, 0);
+    load_q(st_beg + 1);
+    load_stage(st_beg + 2, 0);
+    lds_barrier();
+    for (int st = st_beg; st < st_end; st += 2) {
+      store_stage(1, 1);  // step st+1
+      load_q(st + 2);
+      load_stage(st + 3, 1);
+      multiply(0);
+      lds_barrier();
+      store_stage(0, 0);  // step st+2
+      load_q(st + 3);
+      load_stage(st + 4, 0);
+      if (st + 1 < st_end) multiply(1);
+      lds_barrier();
+    }
   }
-  // ---- fold the accumulators into the dense system (A - S): lower triangle, fp64 atomics
+  // ---- leave the tiles to the fold kernel: no atomics here.  Pair (slot position, pixel range) owns SY_T tiles of 256
+  // floats; a lane stores its four values of tile ti at 4 * lane (row 16 ta + 4 g + x, column 16 tb + r).
+  float* part = v.sy_part[CLS - 1] + ((size_t)(wlin % count) * nrange + range) * (size_t)((CLS == 1 ? SY_T1 : SY_T2) * 256);
 #pragma unroll
   for (int u = 0; u < MAXS; u++) {
     if (mysup[u] >= 0) {
@@ -1678,26 +1795,68 @@ __global__ __launch_bounds__(512, MINWG) void ba_syrk_kernel(BaView v) {
       for (int q = 0; q < 4; q++) {
         const int ta = 2 * sa + (q >> 1), tb = 2 * sb + (q & 1);
         if (ta >= ntr || tb > ta) continue;  // outside the slot / strict upper tile of a diagonal super-tile
+        *reinterpret_cast<f32x4*>(part + (size_t)(ta * (ta + 1) / 2 + tb) * 256 + 4 * lane) = acc[u][q];
+      }
+    }
+  }
+}
+
+// Fold of the dense classes: sums a slot's tiles over its pixel ranges in fp64 and adds ONE fp64 atomic per system entry
+// and slot.  The kernels of rounds 1-2 added one per entry and pixel range from inside the SYRK: 12 M atomics at one rank,
+// and every extra pixel range -- what a shard with 32 slots on 256 CUs needs -- cost another 0.05 ms.  (A device-scope
+// fp64 atomic is a read-modify-write of its line at the memory side, the XCDs' L2s not being coherent: ~128 B of HBM
+// traffic each.  An owner-computes fold -- workgroup p gathers block row p of the system from the slots that hold pose p,
+// LDS accumulation, plain stores -- was built and measured: 135 us against 136 at one rank, 64 against 29 on an
+// 8-way shard, a chain of dependent look-ups per workgroup; profiles/r03_dense_syrk_ab.txt.)
+// grid (M, tile groups, 2 classes); wgs1 / wgs2 = workgroups (x * y) of the two SYRK launches.
+__global__ __launch_bounds__(256) void ba_syrk_fold_kernel(BaView v, int wgs1, int wgs2) {
+  const int cls = (int)blockIdx.z + 1;
+  const int count = min(v.hdr[HDR_NC1 + cls - 1], v.M);
+  const int pos = (int)blockIdx.x;
+  if (pos >= count) return;
+  const int tmax = cls == 1 ? SY_T1 : SY_T2;
+  const int stages_total = v.HW / SY_TPX;
+  const int nrange = max(1, min(min((cls == 1 ? wgs1 : wgs2) / count, SY_MAXSPLIT), stages_total));
+  const int spw = (stages_total + nrange - 1) / nrange;
+  const int nused = (stages_total + spw - 1) / spw;  // ranges that have stages (the others wrote nothing)
+  const int m = v.cls_list[(cls - 1) * (v.nbuf + 2) + pos];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int e0 = v.ent_ptr[m], nent = v.ent_ptr[m + 1] - e0;
+  const int R = 6 * nent;
+  const int ntr = (R + 1 + 15) / 16, ntiles = ntr * (ntr + 1) / 2;
+  __shared__ int s_pose[SLOT_MAXE + 2];
+  for (int i = tid; i < nent; i += (int)blockDim.x) s_pose[i] = v.ent_pose[e0 + i];
+  __syncthreads();
+  const float* part = v.sy_part[cls - 1] + (size_t)pos * nrange * tmax * 256;
+  const int r = lane & 15, g = lane >> 4;
+  for (int ti = (int)blockIdx.y * 4 + wave; ti < ntiles; ti += 4 * (int)gridDim.y) {
+    int ta, tb;
+    tri_coords(ti, ta, tb);
+    double sum[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int rg = 0; rg < nused; rg++) {
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(part + ((size_t)rg * tmax + ti) * 256 + 4 * lane);
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-          const int li = 16 * ta + 4 * g + x;  // row of the slot (A side)
-          const int lj = 16 * tb + r;          // B side, always an E row
-          if (lj >= R || li > R) continue;
-          const double val = -(double)acc[u][q][x];
-          const int gj = 6 * s_pose[lj / 6] + lj % 6;
-          if (li == R) {  // w row: reduced rhs
-            atomicAdd(sys_at(v, v.n, gj), val);
-            continue;
-          }
-          const int gi = 6 * s_pose[li / 6] + li % 6;
-          if (ta == tb) {  // diagonal tile: both (li,lj) and (lj,li) are computed
-            if (gi >= gj) atomicAdd(sys_at(v, gi, gj), val);
-          } else {  // the mirror element is not computed: fold it into the lower triangle
-            if (gi > gj) atomicAdd(sys_at(v, gi, gj), val);
-            else if (gi < gj) atomicAdd(sys_at(v, gj, gi), val);
-            else atomicAdd(sys_at(v, gi, gj), 2.0 * val);
-          }
-        }
+      for (int x = 0; x < 4; x++) sum[x] += (double)pv[x];
+    }
+    const int lj = 16 * tb + r;  // B side, always an E row
+    if (lj >= R) continue;
+    const int gj = 6 * s_pose[lj / 6] + lj % 6;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      const int li = 16 * ta + 4 * g + x;  // row of the slot (A side)
+      if (li > R) continue;
+      const double val = -sum[x];
+      if (li == R) {  // w row: reduced rhs
+        atomicAdd(sys_at(v, v.n, gj), val);
+        continue;
+      }
+      const int gi = 6 * s_pose[li / 6] + li % 6;
+      if (ta == tb) {  // diagonal tile: both (li,lj) and (lj,li) are computed
+        if (gi >= gj) atomicAdd(sys_at(v, gi, gj), val);
+      } else {  // the mirror element is not computed: fold it into the lower triangle
+        if (gi > gj) atomicAdd(sys_at(v, gi, gj), val);
+        else if (gi < gj) atomicAdd(sys_at(v, gj, gi), val);
+        else atomicAdd(sys_at(v, gi, gj), 2.0 * val);
       }
     }
   }
@@ -1961,13 +2120,9 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
         hipLaunchKernelGGL(ba_schur_fused_kernel<true>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
                            intr, weights, ii, jj, wide);
         if (wide) {  // dense slots: SYRK straight from the E rows the linearisation wrote (v.Ebuf)
-          const int stages = v.HW / SY_TPX;
-          int nsw = 256 / (v.M > 0 ? v.M : 1);  // pixel splits: each costs one fp64 atomic per output entry
-          nsw = nsw < 2 ? 2 : (nsw > stages ? stages : nsw);
-          hipLaunchKernelGGL((ba_syrk_kernel<SW_MID, 4, 1, 2>), dim3(v.M, nsw, 2), dim3(512), 0, s, v);
-          int nsb = 256 / (4 * (v.M > 0 ? v.M : 1));
-          nsb = nsb < 2 ? 2 : (nsb > stages ? stages : nsb);
-          hipLaunchKernelGGL((ba_syrk_kernel<SW_BIG, 1, 2, 4>), dim3(v.M, nsb, 4), dim3(512), 0, s, v);
+          hipLaunchKernelGGL((ba_syrk3_kernel<SW_MID, 12, 1, 1, true>), dim3(v.M, v.sy_ns[0], 1), dim3(768), 0, s, v);
+          hipLaunchKernelGGL((ba_syrk3_kernel<SW_BIG, 8, 2, 4, false>), dim3(v.M, v.sy_ns[1], 4), dim3(512), 0, s, v);
+          hipLaunchKernelGGL(ba_syrk_fold_kernel, dim3(v.M, 34, 2), dim3(256), 0, s, v, v.M * v.sy_ns[0], v.M * v.sy_ns[1]);
         }
       }
       break;

@@ -69,11 +69,16 @@ __global__ void chains(const float* A, const float* B, float* C32, float* Ca, fl
 
 int main() {
   for (int K : {64, 512, 1536, 4096}) {
-    for (int sign = 0; sign < 2; sign++) {
+    for (int sign = 0; sign < 3; sign++) {  // 2: positive terms with a wide dynamic range along k (x 2^-12..2^0 per k)
       std::vector<float> A(16 * K), B(16 * K);
       srand(1 + K);
-      for (auto& x : A) x = (sign ? (rand() % 2 ? 1.f : -1.f) : 1.f) * (0.5f + rand() / (float)RAND_MAX);
+      for (auto& x : A) x = (sign == 1 ? (rand() % 2 ? 1.f : -1.f) : 1.f) * (0.5f + rand() / (float)RAND_MAX);
       for (auto& x : B) x = 0.5f + rand() / (float)RAND_MAX;
+      if (sign == 2)
+        for (int k = 0; k < K; k++) {
+          const float sc = ldexpf(1.f, -(rand() % 13));
+          for (int i = 0; i < 16; i++) A[i * K + k] *= sc;
+        }
       float *dA, *dB, *dC;
       hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dC, 4096);
       hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
@@ -82,7 +87,7 @@ int main() {
       float C[1024];
       hipMemcpy(C, dC, 4096, hipMemcpyDeviceToHost);
       const char* name[4] = {"fp32 MFMA chain      ", "bf16x3, one acc      ", "bf16x3, hi / lo accs ", "bf16x3, per-step + add"};
-      printf("K=%5d %s terms:\n", K, sign ? "mixed-sign" : "positive  ");
+      printf("K=%5d %s terms:\n", K, sign == 1 ? "mixed-sign" : (sign ? "positive, wide range" : "positive  "));
       for (int v = 0; v < 4; v++) {
         double bm = 0, rm = 0, mx = 0;
         for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) {

@@ -1,6 +1,6 @@
 """Per-rank compute of the multi-GPU bench emulated on ONE GPU: for world = 1,2,4,8 build the graph, take the shard of
 rank 0 and of a middle rank, and time the local iteration (no collective).  Default: BASELINE configs[3], 8000 edges in
-total (what `bench.py --gpus N` runs); `weak`: 2000 edges per rank.  usage: scale_emul.py [weak]"""
+total (what `bench.py --gpus N` runs); `weak`: 2000 edges per rank.  usage: scale_emul.py [weak] [worlds=1,8]"""
 import sys, time
 WEAK = len(sys.argv) > 1 and sys.argv[1] == "weak"
 import os
@@ -10,7 +10,8 @@ import numpy as np, torch
 from droid_backends import ba_driver, synth
 dev = torch.device("cuda:0")
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-for world in (1, 2, 4, 8):
+WORLDS = [int(x) for a in sys.argv[1:] if a.startswith("worlds=") for x in a[7:].split(",")] or [1, 2, 4, 8]
+for world in WORLDS:
     prob = synth.make_ba_problem(N=256, E=(2000 * world if WEAK else 8000), H=48, W=64, lm=1e-5, ep=1e-2,
                                  seed=synth.CONFIG_SEEDS["cfg3" if WEAK else "cfg4"])
     ranges = ba_driver.partition_frames(prob.ii, 256, world)
