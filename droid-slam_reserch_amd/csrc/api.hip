@@ -57,6 +57,17 @@ static thread_local char g_err[512] = "";
 // workspace -> host-visible status words (droid_ba_attach_status_mirror)
 static std::map<const void*, int*> g_mirror;
 static std::mutex g_mirror_mu;
+// workspace -> launch hints (droid_ba_attach_launch_hints) + tag of the last prepare
+struct HintState { int* ptr; int tag; };
+static std::map<const void*, HintState> g_hint;
+static void hints_of(BaView& v, const void* ws, bool new_call) {
+  std::lock_guard<std::mutex> lock(g_mirror_mu);
+  auto it = g_hint.find(ws);
+  if (it == g_hint.end()) return;
+  if (new_call) it->second.tag = it->second.tag >= (1 << 30) ? 1 : it->second.tag + 1;
+  v.hint = it->second.ptr;
+  v.hint_tag = it->second.tag;
+}
 static int* mirror_of(const void* ws) {
   std::lock_guard<std::mutex> lock(g_mirror_mu);
   auto it = g_mirror.find(ws);
@@ -213,6 +224,7 @@ int droid_ba_prepare(const int64_t* ii, const int64_t* jj, int E, int nbuf, int 
   v.own0 = own0 < 0 ? 0 : own0;
   v.own1 = own1 > nbuf ? nbuf : own1;
   v.motion_only = motion_only ? 1 : 0;
+  hints_of(v, workspace, true);
   launch_prep(v, ii, jj, (hipStream_t)stream);
   // overlap mode: no reduced rows of any iteration of this call are in `sys` yet (epochs start at 1)
   (void)hipMemsetAsync(v.ov_ready, 0, sizeof(int) * ((size_t)(v.n + 1 + CHOL_NB - 1) / CHOL_NB), (hipStream_t)stream);   // (>= block columns)
@@ -229,6 +241,7 @@ static int ba_build_impl(const float* poses, const float* disps, const float* in
   int rc = ba_view(v, workspace, workspace_bytes, E, nbuf, H, W, t0, t1, M, motion_only);
   if (rc) return rc;
   v.packed = packed;
+  hints_of(v, workspace, false);
   if (!poses || !disps || !intrinsics) return fail(DROID_E_ARG, "ba: null %s", "state pointer");
   if (E > 0 && (!targets || !weights || !ii || !jj)) return fail(DROID_E_ARG, "ba: null %s", "edge data");
   if (!motion_only && (!eta || !disps_sens)) return fail(DROID_E_ARG, "ba: null %s", "eta/disps_sens");
@@ -387,6 +400,7 @@ int droid_ba_profile_iteration(float* poses, float* disps, const float* intrinsi
   BaView v;
   int rc = ba_view(v, workspace, workspace_bytes, E, nbuf, H, W, t0, t1, M, motion_only);
   if (rc) return rc;
+  hints_of(v, workspace, false);
   if (!stage_ms) return fail(DROID_E_ARG, "ba_profile: null %s", "stage_ms");
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t ev[8];
@@ -443,6 +457,14 @@ int droid_ba_status(const void* workspace, void* stream, int* status_out, int* d
   }
   if (status_out) *status_out = hdr[HDR_STATUS];
   if (depth_slots_out) *depth_slots_out = hdr[HDR_M];
+  return DROID_OK;
+}
+
+int droid_ba_attach_launch_hints(const void* workspace, int* hints) {
+  if (!workspace) return fail(DROID_E_ARG, "ba_attach_launch_hints: null %s", "workspace");
+  std::lock_guard<std::mutex> lock(g_mirror_mu);
+  if (hints) g_hint[workspace] = HintState{hints, 0};
+  else g_hint.erase(workspace);
   return DROID_OK;
 }
 

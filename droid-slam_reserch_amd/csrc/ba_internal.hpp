@@ -107,6 +107,9 @@ struct BaView {
   float* dx;               // [P][6]
   int* bs_flags;           // [chol_flag_words(n)] hand-off flags of the single-launch factorisation
   double* ldiag;           // [ceil(n/64)][64][64] factored diagonal tiles, then the hand-over slots of the panel tiles
+  int* hint;               // host-side launch hints (droid_ba_attach_launch_hints): 2 ints of page-locked host memory {tag, slots of
+                           // Schur class 3}, written by ba_prep_kernel; nullptr: none.  hint_tag = tag of this workspace's last prepare
+  int hint_tag;
   int* ov_ready;           // [block columns of the system] overlap mode: epoch of the last iteration whose reduced columns are in `sys`
 };
 
@@ -121,6 +124,7 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.n = 6 * v.P; v.ld = chol_ld(v.n);
   v.nch = (v.HW + LIN_CP - 1) / LIN_CP;
   v.own0 = 0; v.own1 = nbuf; v.motion_only = 0;
+  v.hint = nullptr; v.hint_tag = 0;
   size_t off = 0;
   char* base = static_cast<char*>(ws);
   auto take = [&](size_t bytes) {

@@ -374,11 +374,20 @@ __global__ __launch_bounds__(1024) void ba_prep_kernel(BaView vg, const int64_t*
   // its workgroups over the slots that exist instead of leaving most of the grid to exit early
   if (t < 2) v.hdr[HDR_NC1 + t] = 0;
   __syncthreads();  // the rank loop above reads wk_ptr
+  int my3 = 0;
   for (int m = t; m < Ms; m += T) {
     const int nent = v.ent_ptr[m + 1] - v.ent_ptr[m];
-    v.wk_ptr[m] = nent > 0 ? schur_class(6 * nent + 1, v.seg_ptr[m + 1] - v.seg_ptr[m], v.wide) : 0;
+    const int c = nent > 0 ? schur_class(6 * nent + 1, v.seg_ptr[m + 1] - v.seg_ptr[m], v.wide) : 0;
+    v.wk_ptr[m] = c;
+    my3 += (c == 3) ? 1 : 0;
   }
-  __syncthreads();
+  const int n3 = __syncthreads_count(my3);  // (threads, not slots: only "none" matters)
+  if (t == 0 && vg.hint) {
+    // launch hint for the host: with no class-3 slot the block-pair launch of every iteration of this call is empty
+    // and the host may leave it out -- if this store has arrived by the time it enqueues the iteration (it never waits)
+    __hip_atomic_store(vg.hint + 1, n3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(vg.hint, vg.hint_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   for (int m = t; m < Ms; m += T) {
     const int c = v.wk_ptr[m];
     if (c != 1 && c != 2) continue;
@@ -2117,8 +2126,17 @@ void launch_build_stage(const BaView& v, const float* poses, const float* disps,
         hipLaunchKernelGGL(ba_schur2_kernel, dim3(v.M + asm_x, v.s2_split), dim3(256), 0, s, v, poses, disps, intr, weights, ii, jj,
                            wide, asm_units);
         hipLaunchKernelGGL(ba_schur_fold_kernel, dim3(v.M), dim3(1024), 0, s, v, poses, jj, v.s2_split);
-        hipLaunchKernelGGL(ba_schur_fused_kernel<true>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
-                           intr, weights, ii, jj, wide);
+        // slots with more edges than the two kernels above / the SYRK classes below take: block pairs.  Most graphs have
+        // none, and the empty launch costs 5 us of every iteration: left out when ba_prep_kernel's hint says so
+        // (tag = this call's prepare; read without waiting: not there yet = launch)
+        bool none3 = false;
+        if (v.hint) {
+          const int tag = __atomic_load_n(v.hint, __ATOMIC_ACQUIRE);
+          none3 = tag == v.hint_tag && __atomic_load_n(v.hint + 1, __ATOMIC_RELAXED) == 0;
+        }
+        if (!none3)
+          hipLaunchKernelGGL(ba_schur_fused_kernel<true>, dim3(v.M, nsplit), dim3(256), 0, s, v, poses, disps,
+                             intr, weights, ii, jj, wide);
         if (wide) {  // dense slots: SYRK straight from the E rows the linearisation wrote (v.Ebuf)
           hipLaunchKernelGGL((ba_syrk3_kernel<SW_MID, 12, 1, 1, true>), dim3(v.M, v.sy_ns[0], 1), dim3(768), 0, s, v);
           hipLaunchKernelGGL((ba_syrk3_kernel<SW_BIG, 8, 2, 4, false>), dim3(v.M, v.sy_ns[1], 4), dim3(512), 0, s, v);

@@ -39,7 +39,9 @@ class _Workspace:
         self.buf = None
         # {status of the last iteration, depth slots, number of iterations that ended with a violation / a stalled
         # solve so far, OR of their status bits}: written by the device only (include/droid_backends_hip.h)
-        self.mirror = torch.zeros(4, dtype=torch.int32).pin_memory()
+        # words 4, 5: launch hints {tag of the call, its slots of Schur class 3}, written by the call's first kernel and read by
+        # the library -- never waited for -- when it enqueues an iteration (droid_ba_attach_launch_hints)
+        self.mirror = torch.zeros(8, dtype=torch.int32).pin_memory()
         self.seen = 0      # error count already raised / shown to the caller
 
     def get(self, nbytes, device):
@@ -47,8 +49,10 @@ class _Workspace:
             lib = _lib.load()
             if self.buf is not None:
                 lib.droid_ba_attach_status_mirror(self.buf.data_ptr(), None)
+                lib.droid_ba_attach_launch_hints(self.buf.data_ptr(), None)
             self.buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
             _lib.check(lib.droid_ba_attach_status_mirror(self.buf.data_ptr(), self.mirror.data_ptr()), "ba (status mirror)")
+            _lib.check(lib.droid_ba_attach_launch_hints(self.buf.data_ptr(), self.mirror.data_ptr() + 16), "ba (launch hints)")
         return self.buf
 
 

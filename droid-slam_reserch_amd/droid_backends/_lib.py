@@ -22,7 +22,7 @@ SYMBOLS = [
     "droid_ba_packed_system", "droid_ba_unpack_system",
     "droid_ba_overlap_plan", "droid_ba_unpack_chunk", "droid_ba_solve_update_overlap",
     "droid_ba_solve_update", "droid_ba_profile_iteration", "droid_ba_system", "droid_ba_status",
-    "droid_ba_attach_status_mirror", "droid_chol_solve", "droid_chol_scratch_doubles", "droid_reproject_motion",
+    "droid_ba_attach_status_mirror", "droid_ba_attach_launch_hints", "droid_chol_solve", "droid_chol_scratch_doubles", "droid_reproject_motion",
     "droid_frame_distance", "droid_frame_distance_matrix", "droid_projmap", "droid_iproj", "droid_depth_filter",
 ]
 
@@ -77,6 +77,7 @@ def load() -> ctypes.CDLL:
     lib.droid_ba_system.restype = vp
     lib.droid_ba_status.argtypes = [vp, vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.droid_ba_attach_status_mirror.argtypes = [vp, vp]
+    lib.droid_ba_attach_launch_hints.argtypes = [vp, vp]
     lib.droid_chol_solve.argtypes = [vp, vp, vp, c_int, vp, vp, vp]
     lib.droid_reproject_motion.argtypes = [vp, vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp]
     lib.droid_chol_scratch_doubles.argtypes = [c_int]

@@ -78,7 +78,11 @@ class HipBackend:
         if nbytes == 0:
             raise RuntimeError("ba: bad sizes / window")
         if self.ws is None or self.ws.numel() < nbytes:
+            if self.ws is not None:
+                self.lib.droid_ba_attach_launch_hints(self.ws.data_ptr(), None)
             self.ws = torch.empty(nbytes + 4096, dtype=torch.uint8, device=p.poses.device)
+            self.hints = torch.zeros(2, dtype=torch.int32).pin_memory()   # include/droid_backends_hip.h: launch hints
+            _lib.check(self.lib.droid_ba_attach_launch_hints(self.ws.data_ptr(), self.hints.data_ptr()), "ba (launch hints)")
         self._dims = (E, nbuf, H, W, M, t0, t1)
         s = torch.cuda.current_stream().cuda_stream
         _lib.check(self.lib.droid_ba_prepare(p.ii.data_ptr(), p.jj.data_ptr(), E, nbuf, H, W, M, t0, t1,

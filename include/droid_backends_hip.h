@@ -226,6 +226,13 @@ int droid_ba_status(const void *workspace, void *stream, int *status_out, int *d
  * workspaces (droid_backends keeps one per (device, stream)). */
 int droid_ba_attach_status_mirror(const void *workspace, int *mirror);
 
+/* Launch hints (optional): `hints` points to 2 ZEROED ints of page-locked host memory that the device can address.
+ * droid_ba_prepare's kernel then writes {tag of that prepare, number of depth slots of Schur class 3 (more edges than the
+ * regular Schur kernels take: block pairs)} there, and droid_ba_build / droid_ba leave the block-pair launch of an
+ * iteration out when the hint of the CURRENT prepare has arrived and says "none" (most graphs: 5 us per iteration).
+ * The host never waits for the hint: not there yet = launch.  Results do not depend on it.  hints = NULL detaches. */
+int droid_ba_attach_launch_hints(const void *workspace, int *hints);
+
 /* Dense SPD solve used by the BA (exposed for tests): A [n,n] fp64 row-major (lower triangle
  * read, destroyed), b [n] fp64 -> x [n] fp64.  fail_flag (device int) is set to 1 when a pivot
  * is not positive.  scratch (128-byte aligned): >= droid_chol_scratch_doubles(n) doubles (the augmented system

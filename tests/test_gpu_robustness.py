@@ -214,3 +214,29 @@ def test_index_and_dtype_checks_on_the_host(backends):
     with pytest.raises(RuntimeError, match="float32"):
         backends.corr_index_backward(vol, torch.zeros(1, 2, 8, 8, dtype=torch.float64, device="cuda"),
                                      torch.zeros(1, 7, 7, 8, 8, device="cuda"), 3)
+
+
+def test_launch_hints_name_the_block_pair_class_and_do_not_change_results(backends):
+    """The first kernel of a `ba` call tells the host (page-locked words, never waited for) whether the graph has depth slots
+    of the block-pair Schur class; with "none" the library leaves that launch out of the iterations it enqueues after the hint
+    has arrived.  The hint is right for a graph without and one with such slots, and the result is the same with the hints
+    detached (every launch made)."""
+    torch = _torch()
+    import copy
+    import droid_backends as db
+    from droid_backends import synth
+    from util import run_hip_ba
+    lib = db._lib.load()
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    for p, expect_slots in ((synth.make_config("cfg2"), False),
+                            (synth.make_ba_problem(N=30, E=720, H=15, W=20, seed=78, lm=1e-4, ep=0.1), True)):
+        a = run_hip_ba(backends, copy.deepcopy(p), torch, 4)
+        w = db._workspaces[key]
+        tag0 = int(w.mirror[4])
+        assert tag0 >= 1                                            # the hint of the call has arrived
+        assert (int(w.mirror[5]) > 0) == expect_slots, (int(w.mirror[5]), expect_slots)
+        lib.droid_ba_attach_launch_hints(w.buf.data_ptr(), None)
+        b = run_hip_ba(backends, copy.deepcopy(p), torch, 4)
+        assert int(w.mirror[4]) == tag0                             # detached: not written
+        lib.droid_ba_attach_launch_hints(w.buf.data_ptr(), w.mirror.data_ptr() + 16)
+        assert np.abs(a["poses"] - b["poses"]).max() < 1e-6 and np.abs(a["disps"] - b["disps"]).max() < 1e-6
