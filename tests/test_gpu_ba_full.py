@@ -96,6 +96,16 @@ def test_dense_graph_block_pair_kernel_matches_oracle(backends, oracle, synth):
     _parity(backends, oracle, p, 2, "dense 30kf/720e 15x20")
 
 
+def test_dense_graph_with_fewer_stages_than_pixel_ranges(backends, oracle, synth):
+    """Dense slots on a tiny image: 128 pixels are 4 stages of the SYRK kernels, fewer than the pixel ranges their grid
+    would deal out (the split is clamped; ranges without stages write nothing and the fold skips them); slots of 17-19
+    edges (SYRK class 1) next to a few of 16 or less (the sparse kernel) in one graph."""
+    p = synth.make_ba_problem(N=20, E=330, H=8, W=16, seed=5, lm=1e-4, ep=0.1)
+    deg = np.bincount(p.ii, minlength=20)
+    assert deg.max() > 16 and 330 >= 12 * p.eta.shape[0]
+    _parity(backends, oracle, p, 2, "dense 20kf/330e 8x16")
+
+
 @pytest.fixture(scope="module")
 def cfg3_sensitive(oracle, cfg3):
     """Ill-conditioned disparities of the headline graph over two iterations, measured with the oracle alone."""
