@@ -118,6 +118,9 @@ struct BaSizes {
 };
 
 // Carves `ws` (may be null: size query only) into the view.  Host-only arithmetic.
+#ifndef SY_WGS
+#define SY_WGS 1024  // (slot, pixel range) workgroups of the class-1 SYRK launch: four per CU balance the uneven slots (A/B 512 / 768 / 1024 / 1536 / 2048: 270 / 265 / 253 / 262 / 270 us at 256 slots)
+#endif
 inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t0, int t1, int M) {
   v.E = E; v.nbuf = nbuf; v.H = H; v.W = W; v.HW = H * W;
   v.t0 = t0; v.t1 = t1; v.P = t1 - t0; v.M = M;
@@ -156,11 +159,11 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
   v.sy_part[0] = v.sy_part[1] = nullptr;
   v.sy_ns[0] = v.sy_ns[1] = 0;
   if (v.wide) {
-    // pixel splits of the SYRK launches: enough (slot, range) workgroups to fill 256 CUs (class 1: one 12-wave workgroup per
+    // pixel splits of the SYRK launches: enough (slot, range) workgroups to fill 256 CUs four times over (class 1: one 12-wave workgroup per
     // CU; class 2: four shares per pair); a split costs a set of partial tiles, no atomics.  A launch has M * ns pairs at most:
     // 136 (class 1: <= 256 rows) or 528 (class 2: <= 512 rows) tiles of 1 KB each
     const int stages = v.HW / 32;
-    int nsw = (512 + M - 1) / M, nsb = (256 + 4 * M - 1) / (4 * M);
+    int nsw = (SY_WGS + M - 1) / M, nsb = (256 + 4 * M - 1) / (4 * M);
     nsw = nsw < 2 ? 2 : (nsw > stages ? stages : nsw);
     nsb = nsb < 2 ? 2 : (nsb > stages ? stages : nsb);
     v.sy_ns[0] = nsw; v.sy_ns[1] = nsb;

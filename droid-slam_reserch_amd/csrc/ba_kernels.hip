@@ -1779,15 +1779,31 @@ __global__ __launch_bounds__(64 * NWV) void ba_syrk3_kernel(BaView v) {
     load_q(st_beg + 1);
     load_stage(st_beg + 2, 0);
     lds_barrier();
+    // Within a step the conversion (VALU, LDS writes into the other buffer) and the products (LDS reads, matrix pipe) are
+    // independent: half of the waves run them in the opposite order, so that behind every barrier one group reads LDS and
+    // multiplies while the other converts, instead of all twelve waves queueing for the LDS and then for the matrix pipe
+    const bool mul_first = (wave & 1) != 0;  // (two of a SIMD's three waves in one group, one in the other)
     for (int st = st_beg; st < st_end; st += 2) {
+#ifndef SY3_LOCKSTEP
+      if (mul_first) multiply(0);
+#endif
       store_stage(1, 1);  // step st+1
       load_q(st + 2);
       load_stage(st + 3, 1);
+#ifndef SY3_LOCKSTEP
+      if (!mul_first)
+#endif
       multiply(0);
       lds_barrier();
+#ifndef SY3_LOCKSTEP
+      if (mul_first && st + 1 < st_end) multiply(1);
+#endif
       store_stage(0, 0);  // step st+2
       load_q(st + 3);
       load_stage(st + 4, 0);
+#ifndef SY3_LOCKSTEP
+      if (!mul_first)
+#endif
       if (st + 1 < st_end) multiply(1);
       lds_barrier();
     }
