@@ -166,6 +166,8 @@ inline size_t ba_carve(BaView& v, void* ws, int E, int nbuf, int H, int W, int t
     int nsw = (SY_WGS + M - 1) / M, nsb = (256 + 4 * M - 1) / (4 * M);
     nsw = nsw < 2 ? 2 : (nsw > stages ? stages : nsw);
     nsb = nsb < 2 ? 2 : (nsb > stages ? stages : nsb);
+    if (nsw > 16) nsw = 16;  // SY_MAXSPLIT (ba_kernels.hip): the kernels never use more ranges per slot
+    if (nsb > 16) nsb = 16;
     v.sy_ns[0] = nsw; v.sy_ns[1] = nsb;
     v.sy_part[0] = static_cast<float*>(take(sizeof(float) * ((size_t)M * nsw * 136 * 256 + 64)));
     v.sy_part[1] = static_cast<float*>(take(sizeof(float) * ((size_t)M * nsb * 528 * 256 + 64)));

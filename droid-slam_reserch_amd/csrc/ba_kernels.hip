@@ -615,7 +615,10 @@ __global__ __launch_bounds__(LIN_THREADS, 3) void ba_lin_kernel(
     // workgroup sum of the 27 block entries -> Hpart[e][chunk][0..31]
     const float tot = wave_reduce32(acc);
     if ((lane & 1) == 0) red[buf][wave][reduce32_index(lane)] = tot;
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() would also wait for the E-row stores of this edge (dense graphs: 6-12 per thread) and
+    // for the next edge's loads (s_waitcnt vmcnt(0)); nothing that travels through global memory is exchanged here
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (tid < 32) {
       float s = 0.f;
 #pragma unroll
