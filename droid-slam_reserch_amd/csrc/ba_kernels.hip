@@ -1964,20 +1964,33 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
       sm.ent[threadIdx.x] = on ? 1 : 0;
     }
     __syncthreads();
+    // software pipeline: the weights of edge x+1 are in flight while edge x is evaluated (clamped index: no branch
+    // around the loads; an edge that does not feed back costs two loads it does not use)
+    float wnext[BSUB_PPT][2];
+    auto fetch_w = [&](int x) {
+      const float* wg = weights + (size_t)sm.e[min(x, cnt - 1)] * 2 * HW;
+#pragma unroll
+      for (int p = 0; p < BSUB_PPT; p++) {
+        const int kk = kpix[p] < HW ? kpix[p] : 0;
+        wnext[p][0] = wg[kk];
+        wnext[p][1] = wg[HW + kk];
+      }
+    };
+    fetch_w(0);
     for (int x = 0; x < cnt; x++) {
+      float wraw[BSUB_PPT][2];
+#pragma unroll
+      for (int p = 0; p < BSUB_PPT; p++) {
+        const bool ok = kpix[p] < HW;
+        wraw[p][0] = ok ? wnext[p][0] : 0.f;
+        wraw[p][1] = ok ? wnext[p][1] : 0.f;
+      }
+      fetch_w(x + 1);
       const bool edge_on = sm.ent[x] != 0;
       if (!(edge_on || self_on)) continue;
       float T[12];
 #pragma unroll
       for (int n = 0; n < 12; n++) T[n] = sm.T[x][n];
-      const float* wg = weights + (size_t)sm.e[x] * 2 * HW;
-      float wraw[BSUB_PPT][2];
-#pragma unroll
-      for (int p = 0; p < BSUB_PPT; p++) {
-        const bool ok = kpix[p] < HW;
-        wraw[p][0] = ok ? wg[kpix[p]] : 0.f;
-        wraw[p][1] = ok ? wg[HW + kpix[p]] : 0.f;
-      }
 #pragma unroll
       for (int p = 0; p < BSUB_PPT; p++) {
         float eij[6];
