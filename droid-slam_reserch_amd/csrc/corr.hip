@@ -77,6 +77,70 @@ __device__ __forceinline__ Bilin bilin_setup(float x0, float y0, int r) {
   return b;
 }
 
+// ---- the bilinear combine of one query: (2r+1)^2 outputs from (2r+2)^2 taps ---------------------------------
+// out(a, c) = ((tap[c][a] w00 + tap[c+1][a] w01) + tap[c][a+1] w10) + tap[c+1][a+1] w11, every product and every sum rounded
+// to the element type (ck:55-66); output plane a (2r+1) + c.
+template <typename T, int R>
+struct Combine {
+  typedef typename Elem<T>::work work;
+  static constexpr int RD = 2 * R + 1, NT = RD + 1;
+  static __device__ __forceinline__ void run(const work (&tap)[NT][NT], work w00, work w01, work w10, work w11,
+                                             T* __restrict__ out, int H1W1) {
+#pragma unroll
+    for (int a = 0; a < RD; a++) {
+#pragma unroll
+      for (int c = 0; c < RD; c++) {
+        work acc = Elem<T>::mul(tap[c][a], w00);  // 0 + p == p exactly
+        acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a], w01));
+        acc = Elem<T>::add(acc, Elem<T>::mul(tap[c][a + 1], w10));
+        acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a + 1], w11));
+        Elem<T>::store(out + (size_t)(a * RD + c) * H1W1, acc);
+      }
+    }
+  }
+};
+// Half volumes: the same roundings on the packed half ALU, two outputs (x offsets a, a+1) per instruction -- 7 packed
+// instructions per pair instead of 21 fp32 / convert instructions per output (the fp32 form made the lookup VALU-bound at the
+// small pyramid levels: ~1300 instructions per query and level, 26 us per level at 786 432 queries).  Bit-identical:
+//   * tap x weight: both are halves, the product is exact in fp32, so round_half(float(a) * float(b)) -- what c10::Half
+//     does -- IS the correctly rounded half product that v_pk_mul_f16 returns;
+//   * acc + product: both are halves.  If their exponents differ by <= 13 the fp32 sum is exact and both paths round it
+//     once; if by more, the smaller one is below 1/4 of the larger one's half-ulp, so the exact sum, its fp32 rounding and
+//     v_pk_add_f16's single rounding all return the larger operand's neighbourhood identically (no value near a tie).
+// (No FMA: `#pragma clang fp contract(off)` above; f16 denormals are not flushed in either path.)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int R>
+struct Combine<__half, R> {
+  static constexpr int RD = 2 * R + 1, NT = RD + 1;
+  static __device__ __forceinline__ void run(const float (&tap)[NT][NT], float w00, float w01, float w10, float w11,
+                                             __half* __restrict__ out, int H1W1) {
+    // P[j][i] = (tap[j][i], tap[j][i+1]); the taps are halves held in floats: the pack is exact
+    f16x2 P[NT][NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+      for (int i = 0; i < NT; i++)
+        P[j][i] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(tap[j][i], i + 1 < NT ? tap[j][i + 1] : 0.f));
+    const f16x2 W00 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(w00, w00));
+    const f16x2 W01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(w01, w01));
+    const f16x2 W10 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(w10, w10));
+    const f16x2 W11 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(w11, w11));
+    _Float16* o = reinterpret_cast<_Float16*>(out);
+#pragma unroll
+    for (int a = 0; a < RD; a += 2) {
+#pragma unroll
+      for (int c = 0; c < RD; c++) {
+        f16x2 acc = P[c][a] * W00;
+        acc = acc + P[c + 1][a] * W01;
+        acc = acc + P[c][a + 1] * W10;
+        acc = acc + P[c + 1][a + 1] * W11;
+        o[(size_t)(a * RD + c) * H1W1] = acc[0];
+        if (a + 1 < RD) o[(size_t)((a + 1) * RD + c) * H1W1] = acc[1];
+      }
+    }
+  }
+};
+
 // ---- corr_index_forward ------------------------------------------------------------------
 // One thread per query pixel, 64 consecutive pixels per wave: each of the (2r+1)^2 output planes
 // is written as 64 consecutive elements.  A query's window is (2r+2) rows of (2r+2) contiguous
@@ -192,17 +256,7 @@ __global__ __launch_bounds__(256, CORR_MINWG) void corr_index_forward_kernel(con
   const work w10 = Elem<T>::round((work)f32_value(bl.dx * (one - bl.dy)));          // tap (a+1,c  )
   const work w11 = Elem<T>::round((work)f32_value(bl.dx * bl.dy));                  // tap (a+1,c+1)
   T* out = corr + (size_t)b * out_bstride + pix;
-#pragma unroll
-  for (int a = 0; a < RD; a++) {
-#pragma unroll
-    for (int c = 0; c < RD; c++) {
-      work acc = Elem<T>::mul(tap[c][a], w00);  // 0 + p == p exactly
-      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a], w01));
-      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c][a + 1], w10));
-      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a + 1], w11));
-      Elem<T>::store(out + (size_t)(a * RD + c) * H1W1, acc);
-    }
-  }
+  Combine<T, R>::run(tap, w00, w01, w10, w11, out, H1W1);
 }
 
 // Small planes (pyramid level 3 at 48x64: 96 bytes per query in fp16, 192 in fp32): the planes of the 64 queries of a wave
@@ -261,17 +315,7 @@ __global__ __launch_bounds__(64) void corr_index_forward_small(const T* __restri
   const work w10 = Elem<T>::round((work)f32_value(bl.dx * (one - bl.dy)));          // tap (a+1,c  )
   const work w11 = Elem<T>::round((work)f32_value(bl.dx * bl.dy));                  // tap (a+1,c+1)
   T* out = corr + (size_t)b * out_bstride + pix;
-#pragma unroll
-  for (int a = 0; a < RD; a++) {
-#pragma unroll
-    for (int c = 0; c < RD; c++) {
-      work acc = Elem<T>::mul(tap[c][a], w00);  // 0 + p == p exactly
-      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a], w01));
-      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c][a + 1], w10));
-      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a + 1], w11));
-      Elem<T>::store(out + (size_t)(a * RD + c) * H1W1, acc);
-    }
-  }
+  Combine<T, R>::run(tap, w00, w01, w10, w11, out, H1W1);
 }
 
 template <typename T, int R>
@@ -410,17 +454,7 @@ __global__ __launch_bounds__(256) void corr_index_forward_coop(const T* __restri
   const work w10 = Elem<T>::round((work)f32_value(bl.dx * (one - bl.dy)));          // tap (a+1,c  )
   const work w11 = Elem<T>::round((work)f32_value(bl.dx * bl.dy));                  // tap (a+1,c+1)
   T* out = corr + (size_t)b * out_bstride + pix;
-#pragma unroll
-  for (int a = 0; a < RD; a++) {
-#pragma unroll
-    for (int c = 0; c < RD; c++) {
-      work acc = Elem<T>::mul(tap[c][a], w00);  // 0 + p == p exactly
-      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a], w01));
-      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c][a + 1], w10));
-      acc = Elem<T>::add(acc, Elem<T>::mul(tap[c + 1][a + 1], w11));
-      Elem<T>::store(out + (size_t)(a * RD + c) * H1W1, acc);
-    }
-  }
+  Combine<T, R>::run(tap, w00, w01, w10, w11, out, H1W1);
 }
 
 // rows of at most 64 bytes (two or more window rows per 128-byte line), radius 3, half / float
