@@ -581,15 +581,24 @@ def main():
         deg = np.bincount(prob.ii, minlength=Nk)  # Schur GEMM, symmetric minimum
         nk = deg + 1
         schur_flops = float(np.sum((6 * nk) * (6 * nk + 1) * HW + 6 * nk * HW)) * (E_l / max(1, len(prob.ii)))
+        # kernel names as the library dispatches them (ba_internal.hpp::ba_carve): dense graphs (mean out-degree >= 12) run
+        # the linearisation that writes the E rows and the bf16x3 SYRK; few depth slots split a slot's edges over workgroups
+        wide = M_l > 0 and E_l >= 12 * M_l and HW % 32 == 0
+        zsplit = M_l > 0 and 1536 // (M_l * ((HW + 511) // 512)) > 1
+        lin_name = "droid::ba_lin_kernel<true, %s, %s>" % ("true" if wide else "false", "true" if zsplit else "false")
+        schur_name = "droid::ba_syrk3_kernel<256, 12, 1, 1, true>" if wide else "droid::ba_schur2_kernel"
+        schur_note = ("dense-slot Schur SYRK (+ class-2 launch + fold kernel, in the stage time): symmetric-minimum fp32-equivalent flops "
+                      "against the fp32 MFMA peak; executed as six v_mfma_f32_16x16x32_bf16 per 32-deep step on three-way split "
+                      "operands (DESIGN.md section 7)") if wide else (
+                      "Schur SYRK (+ per-slot fold kernel, in the stage time), symmetric-minimum flops, fp32 MFMA peak; the kernel "
+                      "also recomputes the E rows; fp32 MFMA and VALU time add up on gfx950 (tools/micro/mfma_valu_overlap.hip)")
         kernels = [
             flop("droid::chol_factor_persistent_kernel<false>", "factor", n ** 3 / 3.0, FP64_VEC_PEAK_TFLOPS,
                  "fp64 Cholesky of the (6P)^2 reduced camera system in one launch, n^3/3 flops over ceil(n/64) "
                  "dependent block columns: a pivot-latency chain, priced against the fp64 vector/MFMA peak"),
-            hbm("droid::ba_lin_kernel<true, false, false>", "linearize", 16.0 * E_l * HW + 16.0 * M_l * HW + 56.0 * Nk,
+            hbm(lin_name, "linearize", 16.0 * E_l * HW + 16.0 * M_l * HW + 56.0 * Nk,
                 "compulsory bytes of one BA iteration (16*E*HW + 16*M*HW + 56*N)"),
-            flop("droid::ba_schur2_kernel", "schur", schur_flops, 157.3,
-                 "Schur SYRK (+ per-slot fold kernel, in the stage time), symmetric-minimum flops, fp32 MFMA peak; the kernel "
-                 "also recomputes the E rows; fp32 MFMA and VALU time add up on gfx950 (tools/micro/mfma_valu_overlap.hip)"),
+            flop(schur_name, "schur", schur_flops, 157.3, schur_note),
             hbm("droid::ba_backsub_kernel", "update", 8.0 * E_l * HW + 16.0 * M_l * HW,
                 "weights (8*E*HW) + Q, w, disps r/w (16*M*HW)"),
         ]
