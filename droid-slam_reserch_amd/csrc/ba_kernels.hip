@@ -370,7 +370,7 @@ __global__ __launch_bounds__(1024) void ba_prep_kernel(BaView vg, const int64_t*
     v.order[rank] = m;
   }
   if (t == 0) v.hdr[HDR_NWORK] = 0;
-  // compact lists of the slots each SYRK variant serves (ascending slot index), so that ba_syrk_kernel can deal
+  // compact lists of the slots each SYRK variant serves (ascending slot index), so that ba_syrk3_kernel can deal
   // its workgroups over the slots that exist instead of leaving most of the grid to exit early
   if (t < 2) v.hdr[HDR_NC1 + t] = 0;
   __syncthreads();  // the rank loop above reads wk_ptr
@@ -1579,7 +1579,10 @@ __global__ __launch_bounds__(64 * NWV) void ba_syrk3_kernel(BaView v) {
   const int ntr = (R + 1 + 15) / 16;              // 16-row tiles
   const int nst = (ntr + 1) / 2;                  // 32-row super-tile rows
   const int nsup_all = nst * (nst + 1) / 2;       // lower triangle of super-tiles
-  // super-tiles sorted by cost and dealt over shares, SIMDs and waves (see ba_syrk_kernel)
+  // Super-tiles differ in cost: a diagonal one has no use for its strict upper tile (3 of 4 tiles), the last block row of
+  // an odd tile count has one tile row only (2 of 4; 1 in the corner).  They are sorted by cost and dealt out in that
+  // order -- position p to share p % NSHARE, there to the waves back and forth (0..NW-1, NW-1..0, ..) -- so that shares, the
+  // four SIMDs and the waves all carry nearly the same number of MFMAs (13 row tiles: 91 useful tiles of 112).
   __shared__ unsigned char s_cost[NST * (NST + 1) / 2];
   __shared__ short s_sorted[NST * (NST + 1) / 2];
   for (int i = tid; i < nsup_all; i += (int)blockDim.x) {
@@ -1722,11 +1725,7 @@ __global__ __launch_bounds__(64 * NWV) void ba_syrk3_kernel(BaView v) {
     return;
 #endif
     const u32x4* P = PL + buf * 12 * NR;
-#ifdef SY3_NO_LDSREAD
-    auto frag = [&](int chunk) { u32x4 t = {(unsigned)chunk, 1u, 2u, 3u}; asm volatile("" : "+v"(t)); return __builtin_bit_cast(bf16x8, t); };
-#else
     auto frag = [&](int chunk) { return __builtin_bit_cast(bf16x8, P[chunk]); };
-#endif
 #pragma unroll
     for (int u = 0; u < MAXS; u++) {
       if (mysup[u] >= 0) {  // wave-uniform
@@ -1787,27 +1786,17 @@ __global__ __launch_bounds__(64 * NWV) void ba_syrk3_kernel(BaView v) {
     // multiplies while the other converts, instead of all twelve waves queueing for the LDS and then for the matrix pipe
     const bool mul_first = (wave & 1) != 0;  // (two of a SIMD's three waves in one group, one in the other)
     for (int st = st_beg; st < st_end; st += 2) {
-#ifndef SY3_LOCKSTEP
       if (mul_first) multiply(0);
-#endif
       store_stage(1, 1);  // step st+1
       load_q(st + 2);
       load_stage(st + 3, 1);
-#ifndef SY3_LOCKSTEP
-      if (!mul_first)
-#endif
-      multiply(0);
+      if (!mul_first) multiply(0);
       lds_barrier();
-#ifndef SY3_LOCKSTEP
       if (mul_first && st + 1 < st_end) multiply(1);
-#endif
       store_stage(0, 0);  // step st+2
       load_q(st + 3);
       load_stage(st + 4, 0);
-#ifndef SY3_LOCKSTEP
-      if (!mul_first)
-#endif
-      if (st + 1 < st_end) multiply(1);
+      if (!mul_first && st + 1 < st_end) multiply(1);
       lds_barrier();
     }
   }
