@@ -3,7 +3,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 W=${1:-1}
-for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU"; do
+for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --output-format csv --pmc $grp -d $R/gpurun_out/syrkpmc_$tag -- python3 $R/tools/scale_one.py $W 4 > /dev/null 2>&1 || echo "pass failed: $grp"
   f=$(ls -t $R/gpurun_out/syrkpmc_$tag/*/*counter_collection.csv | head -1)
