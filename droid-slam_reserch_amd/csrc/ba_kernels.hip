@@ -615,10 +615,7 @@ __global__ __launch_bounds__(LIN_THREADS, 3) void ba_lin_kernel(
     // workgroup sum of the 27 block entries -> Hpart[e][chunk][0..31]
     const float tot = wave_reduce32(acc);
     if ((lane & 1) == 0) red[buf][wave][reduce32_index(lane)] = tot;
-    // LDS-only barrier: __syncthreads() would also wait for the E-row stores of this edge (dense graphs: 6-12 per thread) and
-    // for the next edge's loads (s_waitcnt vmcnt(0)); nothing that travels through global memory is exchanged here
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __syncthreads();  // (s_waitcnt lgkmcnt(0); s_barrier on this target: the next edge's loads and this edge's stores stay in flight)
     if (tid < 32) {
       float s = 0.f;
 #pragma unroll
@@ -1758,12 +1755,9 @@ __global__ __launch_bounds__(64 * NWV) void ba_syrk3_kernel(BaView v) {
     }
   };
 
-  // __syncthreads() would also drain the global loads in flight (s_waitcnt vmcnt(0)): the LDS traffic is all that has to
-  // be ordered here, the prefetched registers are waited for where they are used
-  auto lds_barrier = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
+  // (__syncthreads() is s_waitcnt lgkmcnt(0); s_barrier on gfx950 -- it orders the LDS traffic and leaves the prefetched global
+  // loads in flight; they are waited for, with counted vmcnt, where their registers are used)
+  auto lds_barrier = [&]() { __syncthreads(); };
   if constexpr (!DBUF) {
     load_q(st_beg);
     load_stage(st_beg, 0);
