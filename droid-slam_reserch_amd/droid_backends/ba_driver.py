@@ -66,6 +66,14 @@ class HipBackend:
         self.lib = _lib.load()
         self.ws = None
 
+    def __del__(self):
+        # the library keys the launch hints by workspace address: drop the registration with the buffers it points to
+        try:
+            if self.ws is not None:
+                self.lib.droid_ba_attach_launch_hints(self.ws.data_ptr(), None)
+        except Exception:
+            pass
+
     def _args(self, p: BAProblemDev, t0, t1, motion_only):
         nbuf, H, W = p.disps.shape
         E = int(p.ii.shape[0])
