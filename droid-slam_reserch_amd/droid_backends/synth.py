@@ -176,8 +176,9 @@ def box5(x):
 
 
 def make_ba_problem(N=8, E=32, H=48, W=64, stereo=False, lm=1e-4, ep=0.1, seed=0, rgbd=False,
-                    nbuf=None, t0=1, radius=3):
-    """SURVEY.md section 8d generator.  Returns float32 arrays shaped like the reference's callers pass."""
+                    nbuf=None, t0=1, radius=3, edges=None):
+    """SURVEY.md section 8d generator.  Returns float32 arrays shaped like the reference's callers pass.
+    edges = (ii, jj): an explicit edge list instead of the band + long-range graph of make_edges (E is ignored)."""
     rng = np.random.default_rng(seed)
     nbuf = N if nbuf is None else nbuf
     intr = np.array([W / 2.0, W / 2.0, W / 2.0, H / 2.0])
@@ -203,7 +204,10 @@ def make_ba_problem(N=8, E=32, H=48, W=64, stereo=False, lm=1e-4, ep=0.1, seed=0
         poses[k, :3], poses[k, 3:] = t, q / np.linalg.norm(q)
     disps = gd.copy()
     disps[:N] = gd[:N] * np.exp(rng.normal(0, 0.1, (N, H, W)))
-    ii, jj = make_edges(N, E, stereo, rng, t0=t0)
+    if edges is None:
+        ii, jj = make_edges(N, E, stereo, rng, t0=t0)
+    else:
+        ii, jj = (np.asarray(x, dtype=np.int64) for x in edges)
     coords, Z = reproject(gt, gd, intr, ii, jj)
     targets = coords + rng.normal(0, 0.25, coords.shape)
     weights = rng.uniform(0, 1, coords.shape)

@@ -106,6 +106,31 @@ def test_dense_graph_with_fewer_stages_than_pixel_ranges(backends, oracle, synth
     _parity(backends, oracle, p, 2, "dense 20kf/330e 8x16")
 
 
+def test_dense_graph_with_every_schur_class(backends, oracle, synth):
+    """One dense graph (mean out-degree >= 12) whose depth slots cover every Schur kernel: window-border frames with <= 16
+    edges (the sparse kernel), the bulk with 18 (SYRK class 1: <= 256 rows), a hub with 68 edges (class 2: <= 512 rows) and a
+    hub connected to every other frame (100 entries = 601 rows: the block-pair kernel, announced by the launch hint)."""
+    N = 100
+    pairs = set()
+    for i in range(N):
+        for d in range(1, 10):
+            for j in (i - d, i + d):
+                if 0 <= j < N:
+                    pairs.add((i, j))
+    for j in range(0, N, 2):
+        if j != 10:
+            pairs.add((10, j))
+    for j in range(N):
+        if j != 20:
+            pairs.add((20, j))
+    pairs = sorted(pairs)
+    ii, jj = [a for a, _ in pairs], [b for _, b in pairs]
+    p = synth.make_ba_problem(N=N, H=8, W=16, seed=11, lm=1e-4, ep=0.1, edges=(ii, jj))
+    deg = np.bincount(p.ii, minlength=N)
+    assert len(ii) >= 12 * p.eta.shape[0] and deg.min() <= 16 and deg[10] + 1 > 42 and 6 * (deg[10] + 1) + 1 <= 512 and deg[20] == N - 1
+    _parity(backends, oracle, p, 2, "dense 100kf hubs 8x16")
+
+
 @pytest.fixture(scope="module")
 def cfg3_sensitive(oracle, cfg3):
     """Ill-conditioned disparities of the headline graph over two iterations, measured with the oracle alone."""
