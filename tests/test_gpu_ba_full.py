@@ -131,6 +131,26 @@ def test_dense_graph_with_every_schur_class(backends, oracle, synth):
     _parity(backends, oracle, p, 2, "dense 100kf hubs 8x16")
 
 
+@pytest.mark.parametrize("variant", ["window_inside_buffer", "rgbd", "stereo_pairs"])
+def test_dense_graph_variants(backends, oracle, synth, variant):
+    """The dense-slot path under the callers' other conventions: an optimisation window that starts at frame 3 inside a longer
+    buffer (fixed frames are sources and targets, their pose blocks are dropped), sensor depth (RGB-D), and stereo pairs
+    (edges i -> i keep their weight in the depth terms only, dk:323, :356)."""
+    N = 24
+    pairs = {(i, j) for i in range(N) for d in range(1, 10) for j in (i - d, i + d) if 0 <= j < N}
+    kw = dict(N=N, H=8, W=32, seed=21, lm=1e-4, ep=0.1)
+    if variant == "window_inside_buffer":
+        kw.update(nbuf=30, t0=3)
+    elif variant == "rgbd":
+        kw.update(rgbd=True)
+    else:
+        pairs |= {(i, i) for i in range(N)}
+    pairs = sorted(pairs)
+    p = synth.make_ba_problem(edges=([a for a, _ in pairs], [b for _, b in pairs]), **kw)
+    assert len(pairs) >= 12 * p.eta.shape[0] and np.bincount(p.ii).max() > 16
+    _parity(backends, oracle, p, 2, f"dense 24kf 8x32 {variant}")
+
+
 @pytest.fixture(scope="module")
 def cfg3_sensitive(oracle, cfg3):
     """Ill-conditioned disparities of the headline graph over two iterations, measured with the oracle alone."""
