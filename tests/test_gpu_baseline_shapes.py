@@ -263,3 +263,30 @@ def test_altcorr_forward_fp16(backends, oracle, lvl):
     assert e_hip < 2e-3                      # a few half ulps of the output scale
     assert e_hip <= 1.5 * e_ref + 1e-3
     assert np.abs(got - half).max() / scale <= 2 * e_ref + 1e-3
+
+
+@pytest.mark.parametrize("C,r,jitter", [(32, 3, 0.5), (96, 3, 6.0), (96, 4, 1.5), (64, 4, 40.0)])
+def test_altcorr_half_wave_kernel_channel_counts_edges_and_diverging_windows(backends, oracle, C, r, jitter):
+    """The f16 wave kernel away from the benchmark shape: 1, 2 and 3 k-steps (C = 32, 64, 96), an image that is no multiple of
+    the 4x4 query tile (10 x 13: masked queries), windows that diverge inside a tile (larger bounding boxes, up to the
+    per-query fallback for incoherent coordinates at jitter 40) and radius 4; fp32 output against the fp64 oracle on the same
+    half inputs."""
+    torch = _torch()
+    rng = np.random.default_rng(7 * C + r)
+    F, H, W = 3, 10, 13
+    fm = (rng.normal(0, 1, (F, H, W, C)) / 4).astype(np.float16)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    ii = np.array([0, 2, 1, 1], dtype=np.int64)
+    jj = np.array([1, 0, 1, 2], dtype=np.int64)
+    E = len(ii)
+    coords = np.stack([xx[None] + rng.uniform(-jitter, jitter, (E, H, W)), yy[None] + rng.uniform(-jitter, jitter, (E, H, W))],
+                      -1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    fused, = backends.altcorr_pyramid_forward([t(fm)], t(coords), t(ii), t(jj), r)
+    assert fused.dtype == torch.float32 and tuple(fused.shape) == (E, (2 * r + 1) ** 2, H, W)
+    ref = oracle.altcorr_forward(fm[ii].astype(np.float64), fm[jj].astype(np.float64), coords[:, None], r,
+                                 acc_dtype=np.float64, chunked=False)[:, 0]
+    scale = np.abs(ref).max()
+    err = np.abs(fused.cpu().numpy() - ref).max() / scale
+    print(f"[half wave kernel C={C} r={r} jitter={jitter}] rel err {err:.2e} (scale {scale:.2f})")
+    assert err < 1e-5
