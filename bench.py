@@ -586,7 +586,7 @@ def main():
         wide = M_l > 0 and E_l >= 12 * M_l and HW % 32 == 0
         zsplit = M_l > 0 and 1536 // (M_l * ((HW + 511) // 512)) > 1
         lin_name = "droid::ba_lin_kernel<true, %s, %s>" % ("true" if wide else "false", "true" if zsplit else "false")
-        schur_name = "droid::ba_syrk3_kernel<256, 12, 1, 1, true>" if wide else "droid::ba_schur2_kernel"
+        schur_name = "droid::ba_syrk3_kernel<256, 12, 1, 1, true, true>" if wide else "droid::ba_schur2_kernel"
         schur_note = ("dense-slot Schur SYRK (+ class-2 launch + fold kernel, in the stage time): symmetric-minimum fp32-equivalent flops "
                       "against the fp32 MFMA peak; executed as six v_mfma_f32_16x16x32_bf16 per 32-deep step on three-way split "
                       "operands (DESIGN.md section 7)") if wide else (
